@@ -1,0 +1,187 @@
+"""bench.py -- the hot path's headline measurement (BASELINE.json metric: attention fp32 TFLOP/s and
+% of MI355X fp32 MFMA peak).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config5_shard] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE pass of the hot path over one batch of synthetic input: one call of the C-ABI entry
+point cmhsa_fp32_fwd (one kernel launch) on inputs already resident in HBM.  Default workload =
+BASELINE.json configs[1]: standalone causal attention fp32, B=1, H=12, T=1024, d_head=64, inputs as
+the model hands them over (QKV column slices of one (T, 3*d_model) buffer).  With N > 1 every rank
+runs the same workload on its own GPU (independent prompts, data-parallel, no collective on the
+data path): weak scaling, value = aggregate over ranks.
+
+Flop convention: F = 2*B*H*d_head*T*(T+1) -- unmasked pairs only, softmax not counted.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "llm-inference_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU x 2.4 GHz (v_mfma_f32_32x32x2_f32)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "config2": dict(B=1, H=12, T=1024, desc="standalone causal attention fp32 B=1 H=12 T=1024 d_head=64 (QKV-sliced inputs)"),
+    # one GPU's share of BASELINE.json configs[4] (B=32, H=16, T=4096 head-sharded 8 ways -> 2 heads per GPU)
+    "config5_shard": dict(B=32, H=2, T=4096, desc="one GPU's head shard of B=32 H=16 T=4096 d_head=64 (2 heads)"),
+}
+
+
+def cpu_baseline(wl: dict, budget_s: float = 20.0) -> dict:
+    """The reference's CPU path (naive PyTorch formula on CPU tensors, restated in oracle/), timed on
+    this host's cores on a bounded sample of the same workload."""
+    from oracle import naive_attention as oracle
+
+    cores = os.cpu_count() or 1
+    cores = min(cores, 16) if "GRAFT_REPO_ROOT" in os.environ else cores   # the GPU box's CPU share is 16
+    torch.set_num_threads(cores)
+    B = min(wl["B"], 2)                      # bounded sample: at most 2 batch rows of the workload
+    H, T = wl["H"], wl["T"]
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.rand((B, T, 64 * H), generator=g) for _ in range(3))
+    oracle.naive_attention_torch(q, k, v, H)             # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 9 and (len(times) < 5 or time.perf_counter() < t_end):
+        t0 = time.perf_counter()
+        oracle.naive_attention_torch(q, k, v, H)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    flops = 2.0 * B * H * 64 * T * (T + 1)
+    return {"value": flops / med / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} runs of naive attention (oracle/naive_attention.py, torch {torch.__version__} CPU ops) "
+                      f"at B={B} H={H} T={T}, median {med * 1e3:.2f} ms"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="config2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP attention path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cmhsa
+
+    lib = cmhsa.load_library()
+    wl = WORKLOADS[args.workload]
+    B, H, T = wl["B"], wl["H"], wl["T"]
+    d = 64 * H
+    torch.manual_seed(1234 + rank)
+    qkv = torch.rand((B, T, 3 * d), device=dev)                      # reference test distribution (test_torch_extension.py:16-18)
+    Q, K, V = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]      # row stride 3*d_model, as in the model
+    out = torch.empty((B, T, d), device=dev)
+    stream = torch.cuda.current_stream(dev)
+    call_args = (Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
+                 Q.stride(1), K.stride(1), V.stride(1), out.stride(1),
+                 Q.stride(0), K.stride(0), V.stride(0), out.stride(0),
+                 B, T, H, 64, ctypes.c_void_p(stream.cuda_stream))
+    fwd = lib.cmhsa_fp32_fwd
+
+    def step() -> None:
+        rc = fwd(*call_args)
+        if rc != 0:
+            raise RuntimeError(cmhsa.status_string(rc))
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)          # same stream the kernel is launched on
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    fence()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    # parity spot-check outside the timed region: one (batch, head) against the f64 oracle
+    from oracle import naive_attention as oracle
+    sl = slice(64 * (H - 1), 64 * H)
+    want = oracle.naive_attention_f64(Q[B - 1, :, sl].cpu().numpy(), K[B - 1, :, sl].cpu().numpy(), V[B - 1, :, sl].cpu().numpy(), 1)
+    max_err = float(abs(out[B - 1, :, sl].cpu().numpy() - want).max())
+
+    if world > 1:
+        tmax = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(tmax[0]), float(tmax[1])
+
+    flops = cmhsa.algorithmic_flops(B, T, H, 64)
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * flops / (wall / args.steps) / 1e12
+    launch_us = dev_ms * 1e3 / args.steps
+    achieved = flops / (dev_ms * 1e-3 / args.steps) / 1e12
+    result = {
+        "metric": "attention fp32 TFLOP/s (causal MHSA forward, F = 2*B*H*d*T*(T+1))",
+        "value": round(value, 3),
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 6),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (torch.rand U[0,1), seeded), inputs resident in HBM",
+        "config": {"workload": wl["desc"], "batch_per_gpu": B, "num_heads": H, "seq_len": T, "head_dim": 64,
+                   "parallelism": f"dp{world} (independent prompts per GPU, no data-path collective)"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": "cmhsa_fwd_kernel", "avg_launch_us": round(launch_us, 3),
+                     "flops_per_launch": flops, "bytes_per_launch_algorithmic": 4 * B * T * d * 4,
+                     "timing": "HIP events on the launch stream around the timed steps (includes inter-launch gaps)"},
+        "percent_of_fp32_mfma_peak": round(100 * achieved / FP32_MFMA_PEAK_TFLOPS, 2),
+        "max_abs_err_vs_f64_oracle": max_err,
+        "device": torch.cuda.get_device_name(dev),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

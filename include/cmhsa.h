@@ -1,0 +1,80 @@
+/* cmhsa.h -- C ABI of the MI355X-native fp32 causal multi-head self-attention forward.
+ *
+ * This is the drop-in boundary under the reference's torch op
+ *   causal_multihead_self_attention::causal_multihead_self_attention_torch(Tensor Q, Tensor K,
+ *                                                    Tensor V, int num_heads) -> Tensor
+ * (reference torch_extensions/causal_multihead_self_attention/causal_multihead_self_attention.cu
+ *  :464-525, abbreviated CMHSA.cu below).  The library (libcmhsa_hip.so) holds hand-written
+ * gfx950 kernels only; it has no torch types, allocates nothing, never synchronises and is
+ * re-entrant.  The torch binding (llm-inference_amd/csrc/torch_binding.cpp) does validation,
+ * torch::empty and the current-stream lookup exactly where CMHSA.cu:464-515 does them.
+ *
+ * All pointers are DEVICE pointers to fp32; strides are in ELEMENTS (floats).
+ */
+#ifndef CMHSA_H
+#define CMHSA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes (0 = success; negative = argument error; positive = hipError_t of a failed
+ * runtime call).  Replaces CMHSA.cu:24-31 (gpuAssert -> exit) and :432-449
+ * (std::invalid_argument): nothing here throws or exits. */
+#define CMHSA_OK                 0
+#define CMHSA_ERR_NULL_POINTER  -1   /* a tensor pointer is NULL while its size is non-zero        */
+#define CMHSA_ERR_BAD_SHAPE     -2   /* batch/seq_len/num_heads negative or num_heads == 0         */
+#define CMHSA_ERR_HEAD_DIM      -3   /* head_dim != 64          (CMHSA.cu:432 "Head dimension must be 64") */
+#define CMHSA_ERR_ALIGNMENT     -4   /* pointer not 16-B aligned or stride % 4 != 0 (CMHSA.cu:480-486)     */
+#define CMHSA_ERR_TOO_LARGE     -5   /* grid or 32-bit tile index would overflow                   */
+
+/* Human-readable text for a status code returned by this library (static storage). */
+const char *cmhsa_status_string(int status);
+
+/* Library/ABI version: (major << 16) | minor. */
+int cmhsa_version(void);
+
+/* Causal multi-head self-attention forward, fp32 in / fp32 out, head_dim = 64.
+ *
+ * Replaces the launcher causal_multihead_self_attention() (CMHSA.cu:409-462) and the kernel it
+ * launches (CMHSA.cu:64-405).  Per (batch b, head h):
+ *     O[b, :, 64h:64h+64] = softmax( mask( Q_h K_h^T ) / sqrt(64) ) V_h ,   key j <= query i.
+ *
+ *   q, k, v    : (batch, seq_len, num_heads*64) views; element (b, t, c) is at
+ *                ptr[b*batch_stride + t*row_stride + c]   (column stride 1, as CMHSA.cu:480-482).
+ *                In the model they are column slices of one (T, 3*d_model) buffer with
+ *                row_stride = 3*d_model (reference causal_self_attention.py:224-227).
+ *   o          : same indexing; every element of (batch, seq_len, num_heads*64) is written,
+ *                so the buffer may come from torch::empty (CMHSA.cu:498).
+ *   batch      : the reference supports only batch 1 (causal_self_attention.py:103-106); here it is
+ *                an extra, independent grid dimension.  batch*_stride is ignored when batch == 1.
+ *   head_dim   : must be 64 (CMHSA.cu:432).  d_model = num_heads*64 is NOT restricted to the
+ *                reference's {768,1024,1280,1600} (CMHSA.cu:435-449): any num_heads >= 1 works.
+ *   stream     : a hipStream_t (NULL = the legacy default stream the reference launches on,
+ *                CMHSA.cu:437).  The launch is asynchronous; no host synchronisation.
+ *
+ * seq_len == 0 or batch == 0 is a successful no-op.  Inputs are read-only and must not alias o.
+ */
+int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
+                   int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                   int64_t q_batch_stride, int64_t k_batch_stride, int64_t v_batch_stride, int64_t o_batch_stride,
+                   int batch, int seq_len, int num_heads, int head_dim,
+                   void *stream);
+
+/* Convenience form of the reference's exact contract: 2-D (N, d_model) tensors, batch 1
+ * (CMHSA.cu:476-478, :488-489, :500-512).  Equivalent to cmhsa_fp32_fwd(..., batch = 1). */
+int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,
+                      int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                      int seq_len, int d_model, int num_heads,
+                      void *stream);
+
+/* Algorithmic work of one call, the figure every TFLOP/s number in this repo uses
+ * (SURVEY.md section 8(d)):  F = 2 * batch * num_heads * head_dim * T * (T+1). */
+double cmhsa_algorithmic_flops(int batch, int seq_len, int num_heads, int head_dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMHSA_H */

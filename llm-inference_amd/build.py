@@ -1,0 +1,79 @@
+"""In-tree build of the MI355X attention library and its torch binding.
+
+    python llm-inference_amd/build.py [--force]
+
+Produces (all git-ignored, all shipped to the GPU box by gpurun):
+  llm-inference_amd/lib/libcmhsa_hip.so                       hand-written gfx950 kernels + C ABI
+  llm-inference_amd/causal_multihead_self_attention.<abi>.so  torch binding / importable module
+
+The reference builds its extension with torch.utils.cpp_extension.CUDAExtension
+(reference torch_extensions/causal_multihead_self_attention/setup.py:4-12); here the kernel
+library is plain `hipcc --offload-arch=gfx950` (no hipify pass, no torch headers), and the
+binding is one host-only C++ file compiled against torch's headers.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+INCLUDE = os.path.join(ROOT, "include")
+ROCM = os.environ.get("ROCM_HOME", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+
+KERNEL_LIB = os.path.join(LIBDIR, "libcmhsa_hip.so")
+EXT_NAME = "causal_multihead_self_attention"
+EXT_PATH = os.path.join(HERE, EXT_NAME + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def _stale(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd: list[str]) -> None:
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build_kernel_lib(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, "cmhsa_fwd.hip"), os.path.join(INCLUDE, "cmhsa.h")]
+    if force or _stale(KERNEL_LIB, srcs):
+        os.makedirs(LIBDIR, exist_ok=True)
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-I" + INCLUDE, "-o", KERNEL_LIB, srcs[0]])
+    return KERNEL_LIB
+
+
+def build_torch_binding(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, "torch_binding.cpp"), os.path.join(INCLUDE, "cmhsa.h"), KERNEL_LIB]
+    if force or _stale(EXT_PATH, srcs):
+        import torch
+        from torch.utils import cpp_extension
+
+        tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+        inc = ["-I" + p for p in cpp_extension.include_paths()]
+        abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared",
+              "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}",
+              "-I" + INCLUDE, "-I" + os.path.join(ROCM, "include"), "-I" + sysconfig.get_paths()["include"],
+              *inc, srcs[0], "-o", EXT_PATH,
+              "-L" + LIBDIR, "-lcmhsa_hip", "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
+              "-Wl,-rpath,$ORIGIN/lib", "-Wl,-rpath," + tlib, "-Wl,--no-as-needed"])
+    return EXT_PATH
+
+
+def build_all(force: bool = False) -> None:
+    build_kernel_lib(force)
+    build_torch_binding(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,128 @@
+"""ctypes view of the C ABI in include/cmhsa.h (libcmhsa_hip.so).
+
+This is the host-side plumbing only: device memory and streams come from PyTorch-ROCm, the
+arithmetic is entirely in the hand-written gfx950 kernels.  There is NO fallback: if the library
+is missing or no GPU is present, the calls raise.
+
+The torch op `torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_torch`
+(registered by importing the sibling extension module `causal_multihead_self_attention`, as the
+reference does at causal_self_attention.py:60-63) goes through the same entry point,
+`cmhsa_fp32_fwd`; tests call both.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # must be imported BEFORE the library: both must share torch's libamdhip64
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcmhsa_hip.so")
+
+# every symbol include/cmhsa.h declares; tests/test_abi.py checks the header against this list
+EXPORTED_SYMBOLS = (
+    "cmhsa_status_string",
+    "cmhsa_version",
+    "cmhsa_fp32_fwd",
+    "cmhsa_fp32_fwd_2d",
+    "cmhsa_algorithmic_flops",
+)
+
+CMHSA_OK = 0
+CMHSA_ERR_NULL_POINTER = -1
+CMHSA_ERR_BAD_SHAPE = -2
+CMHSA_ERR_HEAD_DIM = -3
+CMHSA_ERR_ALIGNMENT = -4
+CMHSA_ERR_TOO_LARGE = -5
+
+_lib = None
+
+
+class CmhsaError(RuntimeError):
+    def __init__(self, status: int, text: str):
+        super().__init__(f"cmhsa status {status}: {text}")
+        self.status = status
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libcmhsa_hip.so (once) and declare the prototypes of include/cmhsa.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python llm-inference_amd/build.py` "
+            "(there is no CPU or PyTorch fallback for the HIP attention path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    i64, i32, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+    lib.cmhsa_status_string.restype = ctypes.c_char_p
+    lib.cmhsa_status_string.argtypes = [i32]
+    lib.cmhsa_version.restype = i32
+    lib.cmhsa_version.argtypes = []
+    lib.cmhsa_fp32_fwd.restype = i32
+    lib.cmhsa_fp32_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp]
+    lib.cmhsa_fp32_fwd_2d.restype = i32
+    lib.cmhsa_fp32_fwd_2d.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp]
+    lib.cmhsa_algorithmic_flops.restype = ctypes.c_double
+    lib.cmhsa_algorithmic_flops.argtypes = [i32, i32, i32, i32]
+    _lib = lib
+    return lib
+
+
+def status_string(status: int) -> str:
+    return load_library().cmhsa_status_string(status).decode()
+
+
+def algorithmic_flops(batch: int, seq_len: int, num_heads: int, head_dim: int = 64) -> float:
+    """F = 2*B*H*d*T*(T+1); pure host arithmetic, no GPU needed."""
+    return float(load_library().cmhsa_algorithmic_flops(batch, seq_len, num_heads, head_dim))
+
+
+def _check(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA tensor")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32")
+    if t.dim() not in (2, 3):
+        raise ValueError(f"{name} must be a 2D (N, d_model) or 3D (B, N, d_model) tensor")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}'s last-dim stride must be 1")
+
+
+def attention_fwd_raw(q_ptr: int, k_ptr: int, v_ptr: int, o_ptr: int,
+                      row_strides, batch_strides, batch: int, seq_len: int, num_heads: int, head_dim: int,
+                      stream: int = 0) -> int:
+    """Direct call of cmhsa_fp32_fwd with raw device addresses; returns the status code."""
+    return load_library().cmhsa_fp32_fwd(
+        q_ptr, k_ptr, v_ptr, o_ptr, *[int(s) for s in row_strides], *[int(s) for s in batch_strides],
+        batch, seq_len, num_heads, head_dim, ctypes.c_void_p(stream))
+
+
+def attention_fwd(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: int,
+                  out: torch.Tensor | None = None) -> torch.Tensor:
+    """Causal multi-head self-attention forward through the C ABI, on torch's current stream.
+
+    Q, K, V: (N, d_model) or (B, N, d_model) fp32 device tensors, last-dim stride 1, arbitrary
+    row stride (multiple of 4).  Returns a new contiguous tensor unless `out` is given.
+    """
+    for t, n in ((Q, "Q"), (K, "K"), (V, "V")):
+        _check(t, n)
+    if K.shape != Q.shape or V.shape != Q.shape:
+        raise ValueError("Q, K and V must have the same shape")
+    d_model = Q.shape[-1]
+    if num_heads <= 0 or d_model % num_heads != 0:
+        raise ValueError("Feature dimension of Q must be evenly divisible by the number of heads")
+    if out is None:
+        out = torch.empty(Q.shape, dtype=torch.float32, device=Q.device)
+    batched = Q.dim() == 3
+    B = Q.shape[0] if batched else 1
+    N = Q.shape[-2]
+    bs = [t.stride(0) if batched else 0 for t in (Q, K, V, out)]
+    rs = [t.stride(-2) for t in (Q, K, V, out)]
+    with torch.cuda.device(Q.device):
+        stream = torch.cuda.current_stream(Q.device).cuda_stream
+        rc = attention_fwd_raw(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), rs, bs,
+                               B, N, num_heads, d_model // num_heads, stream)
+    if rc != CMHSA_OK:
+        raise CmhsaError(rc, status_string(rc))
+    return out

@@ -1,0 +1,90 @@
+// torch_binding.cpp -- thin PyTorch-ROCm binding over the C ABI of include/cmhsa.h.
+//
+// Mirrors the reference's torch-op boundary (reference torch_extensions/
+// causal_multihead_self_attention/causal_multihead_self_attention.cu:464-525, "CMHSA.cu"):
+//   * importable top-level module `causal_multihead_self_attention` whose import registers the op
+//     (reference causal_self_attention.py:60-63, test_torch_extension.py:3; empty module body as
+//     CMHSA.cu:39);
+//   * schema `causal_multihead_self_attention::causal_multihead_self_attention_torch(Tensor Q,
+//     Tensor K, Tensor V, int num_heads) -> Tensor` (CMHSA.cu:517-521) -- argument NAMES are part of
+//     the ABI because the call site uses keywords (causal_self_attention.py:144);
+//   * implementation registered for dispatch key CUDA (CMHSA.cu:523-525), which is the key HIP
+//     tensors carry under PyTorch-ROCm.
+// Differences, all supersets: (B, T, d_model) inputs are accepted next to the reference's 2-D
+// (N, d_model); the launch goes on torch's CURRENT stream instead of the legacy default stream
+// (CMHSA.cu:437); device errors raise instead of exit()ing the process (CMHSA.cu:24-31).
+// All compute is in libcmhsa_hip.so; nothing here touches tensor data.
+
+#include <Python.h>
+
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "cmhsa.h"
+
+namespace causal_multihead_self_attention {
+
+static void check_one(const at::Tensor &t, const char *name, int64_t dim) {
+    TORCH_CHECK(t.is_cuda(), name, " must be a CUDA tensor");                       // CMHSA.cu:468-470
+    TORCH_CHECK(t.dtype() == at::kFloat, name, " must be float32");                 // CMHSA.cu:472-474
+    TORCH_CHECK(t.dim() == dim, name, " must be a ", dim, "D tensor");              // CMHSA.cu:476-478
+    TORCH_CHECK(t.stride(dim - 1) == 1, name, "'s last-dim stride must be 1 for float4 loads to work");      // :480-482
+    TORCH_CHECK(t.stride(dim - 2) % 4 == 0, name, "'s row stride must be a multiple of 4 for float4 loads to work");  // :484-486
+    if (dim == 3) TORCH_CHECK(t.stride(0) % 4 == 0, name, "'s batch stride must be a multiple of 4 for float4 loads to work");
+}
+
+at::Tensor causal_multihead_self_attention_torch(at::Tensor Q, at::Tensor K, at::Tensor V, int64_t num_heads) {
+    const int64_t dim = Q.dim();
+    TORCH_CHECK(dim == 2 || dim == 3, "Q must be a 2D tensor (or 3D: batch, sequence, feature)");
+    check_one(Q, "Q", dim);
+    check_one(K, "K", dim);
+    check_one(V, "V", dim);
+    TORCH_CHECK(K.device() == Q.device() && V.device() == Q.device(), "Q, K and V must be on the same device");
+
+    const int64_t B = dim == 3 ? Q.size(0) : 1;
+    const int64_t N = Q.size(dim - 2);
+    const int64_t d = Q.size(dim - 1);
+    TORCH_CHECK(K.size(dim - 2) == N, "K must have the same sequence length as Q");      // CMHSA.cu:491-494
+    TORCH_CHECK(V.size(dim - 2) == N, "V must have the same sequence length as Q");
+    TORCH_CHECK(K.size(dim - 1) == d, "K must have the same feature dimension as Q");
+    TORCH_CHECK(V.size(dim - 1) == d, "V must have the same feature dimension as Q");
+    if (dim == 3) TORCH_CHECK(K.size(0) == B && V.size(0) == B, "K and V must have the same batch size as Q");
+    TORCH_CHECK(num_heads > 0 && d % num_heads == 0,
+                "Feature dimension of Q must be evenly divisible by the number of heads");   // CMHSA.cu:496
+    TORCH_CHECK(d / num_heads == 64, "Head dimension must be 64.");                         // CMHSA.cu:432-434
+    TORCH_CHECK(B <= INT32_MAX && N <= INT32_MAX && num_heads <= INT32_MAX, "shape exceeds 32-bit indexing");
+
+    at::Tensor output = at::empty(Q.sizes(), Q.options().memory_format(c10::MemoryFormat::Contiguous));  // CMHSA.cu:498
+    if (output.numel() == 0) return output;
+
+    const c10::hip::HIPGuard guard(Q.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(Q.device().index()).stream();
+    auto bs = [&](const at::Tensor &t) -> int64_t { return dim == 3 ? t.stride(0) : 0; };
+    const int rc = cmhsa_fp32_fwd(Q.data_ptr<float>(), K.data_ptr<float>(), V.data_ptr<float>(), output.data_ptr<float>(),
+                                  Q.stride(dim - 2), K.stride(dim - 2), V.stride(dim - 2), output.stride(dim - 2),
+                                  bs(Q), bs(K), bs(V), bs(output),
+                                  (int)B, (int)N, (int)num_heads, (int)(d / num_heads), stream);
+    TORCH_CHECK(rc == CMHSA_OK, "cmhsa_fp32_fwd failed (", rc, "): ", cmhsa_status_string(rc));
+    return output;
+}
+
+TORCH_LIBRARY(causal_multihead_self_attention, m) {
+    m.def("causal_multihead_self_attention_torch(Tensor Q, Tensor K, Tensor V, int num_heads) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
+    m.impl("causal_multihead_self_attention_torch", &causal_multihead_self_attention_torch);
+}
+
+}  // namespace causal_multihead_self_attention
+
+// The module body is empty, as in the reference (CMHSA.cu:39): importing it is what registers the op.
+static struct PyModuleDef cmhsa_module = {
+    PyModuleDef_HEAD_INIT, "causal_multihead_self_attention",
+    "MI355X-native fp32 causal multi-head self-attention (registers "
+    "torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_torch)",
+    -1, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+PyMODINIT_FUNC PyInit_causal_multihead_self_attention(void) { return PyModule_Create(&cmhsa_module); }

@@ -1,0 +1,222 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the hand-written HIP kernel, called through the
+C ABI (ctypes -> cmhsa_fp32_fwd) and through the torch op, against
+  * the golden vectors made by the reference module (tests/golden/*.npz),
+  * the CPU oracle (oracle/naive_attention.py) on the same seeded inputs,
+  * size-independent properties at the BASELINE.json sizes.
+
+Tolerance: north_star states max-abs-error <= 1e-4 in fp32.  The
+reference's own test uses 1e-6 on U[0,1) inputs (test_torch_extension.py:7); we assert the
+1e-4 contract everywhere and additionally hold the U[0,1) sweep to 2e-6 (the reference formula
+itself sits 1e-6 away from an fp64 evaluation at T=1024, see tests/golden/make_golden.py output).
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import cmhsa
+from causal_self_attention import (CausalSelfAttention, ScaledDotProductAttentionBackend,
+                                   scaled_dot_product_attention)
+from oracle import naive_attention as oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4            # north_star contract
+TOL_RAND = 2e-6       # U[0,1) inputs, the reference test's regime
+CUSTOM = ScaledDotProductAttentionBackend.CUSTOM_CUDA
+NAIVE = ScaledDotProductAttentionBackend.NAIVE_PYTORCH
+
+
+def _dev(arrs, device):
+    """numpy (possibly strided views of one buffer) -> device tensors with the SAME strides."""
+    base = arrs[0].base
+    if base is not None and all(a.base is base for a in arrs):
+        buf = torch.from_numpy(base).to(device)
+        d = arrs[0].shape[-1]
+        return tuple(buf[..., i * d:(i + 1) * d] for i in range(3))
+    return tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in arrs)
+
+
+@pytest.mark.parametrize("name", list(cases.ATTENTION_CASES))
+def test_golden_vectors_through_c_abi(name, gpu_device):
+    case = cases.ATTENTION_CASES[name]
+    Q, K, V = _dev(cases.make_inputs(case), gpu_device)
+    if case["layout"] == "qkv":
+        assert Q.stride(0) == 3 * case["d_model"]          # the kernel sees the model's strided views
+    out = cmhsa.attention_fwd(Q, K, V, case["H"])
+    torch.cuda.synchronize()
+    z = np.load(cases.golden_path(name))
+    err = np.abs(out.cpu().numpy()[z["rows"]] - z["expected"]).max()
+    assert err <= (TOL_RAND if case["dist"] == "rand" else TOL), err
+    assert out.is_contiguous() and out.shape == Q.shape
+
+
+def test_reference_sweep_seq_len_1_to_199(gpu_device):
+    """Counterpart of reference test_torch_extension.py:11-22: H=12, d_model=768, seq_len 1..199,
+    torch.rand inputs, custom backend vs the naive formula -- same call shapes, through the torch op."""
+    import causal_multihead_self_attention  # noqa: F401  (registers the op, test_torch_extension.py:3)
+
+    torch.manual_seed(0)
+    worst = 0.0
+    for seq_len in range(1, 200):
+        Q, K, V = (torch.rand((1, seq_len, 768), device=gpu_device) for _ in range(3))
+        got = scaled_dot_product_attention(CUSTOM, queries=Q, keys=K, values=V, num_heads=12, causal_mask=None)
+        want = oracle.naive_attention_torch(Q.cpu(), K.cpu(), V.cpu(), 12)
+        worst = max(worst, (got.cpu() - want).abs().max().item())
+        assert got.shape == (1, seq_len, 768)
+    assert worst <= TOL_RAND, worst
+
+
+def test_sweep_randn_against_f64_oracle(gpu_device):
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for T in (1, 2, 3, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 160, 255, 256, 257):
+        q, k, v = (rng.standard_normal((T, 768), dtype=np.float32) for _ in range(3))
+        out = cmhsa.attention_fwd(*_dev((q, k, v), gpu_device), 12).cpu().numpy()
+        worst = max(worst, np.abs(out - oracle.naive_attention_f64(q, k, v, 12)).max())
+    assert worst <= TOL, worst
+
+
+@pytest.mark.parametrize("d_model,H", [(768, 12), (1024, 16), (1280, 20), (1600, 25), (64, 1), (192, 3)])
+def test_all_model_widths_t1024_strided(d_model, H, gpu_device):
+    """T=1024 (the reference's max context), every GPT-2 width (CMHSA.cu:435-449) plus odd head
+    counts, inputs as QKV slices.  Checked on a head subset against the f64 oracle."""
+    rng = np.random.default_rng(d_model)
+    T = 1024
+    buf = rng.standard_normal((T, 3 * d_model), dtype=np.float32)
+    q, k, v = buf[:, :d_model], buf[:, d_model:2 * d_model], buf[:, 2 * d_model:]
+    out = cmhsa.attention_fwd(*_dev((q, k, v), gpu_device), H).cpu().numpy()
+    for h in sorted({0, H // 2, H - 1}):
+        sl = slice(64 * h, 64 * h + 64)
+        want = oracle.naive_attention_f64(q[:, sl], k[:, sl], v[:, sl], 1)
+        assert np.abs(out[:, sl] - want).max() <= TOL
+
+
+def test_torch_op_equals_c_abi_bitwise(gpu_device):
+    import causal_multihead_self_attention  # noqa: F401
+
+    torch.manual_seed(1)
+    qkv = torch.randn(300, 3 * 768, device=gpu_device)
+    Q, K, V = qkv[:, :768], qkv[:, 768:1536], qkv[:, 1536:]
+    a = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_torch(Q=Q, K=K, V=V, num_heads=12)
+    b = cmhsa.attention_fwd(Q, K, V, 12)
+    assert torch.equal(a, b)
+    assert a.shape == (300, 768) and a.is_contiguous()
+
+
+def test_batched_rows_equal_single_calls(gpu_device):
+    torch.manual_seed(2)
+    B, T, H = 5, 173, 16           # B*H = 80, divisible by 8 -> exercises the XCD-aware block map
+    x = torch.randn(B, T, 3 * 64 * H, device=gpu_device)
+    Q, K, V = x[..., :1024], x[..., 1024:2048], x[..., 2048:]
+    out = cmhsa.attention_fwd(Q, K, V, H)
+    for b in range(B):
+        single = cmhsa.attention_fwd(Q[b], K[b], V[b], H)      # H = 16: plain block map
+        assert torch.equal(out[b], single)
+    want = oracle.naive_attention_f64(Q[1].cpu().numpy(), K[1].cpu().numpy(), V[1].cpu().numpy(), H)
+    assert np.abs(out[1].cpu().numpy() - want).max() <= TOL
+
+
+def test_online_softmax_rescale_is_forced(gpu_device):
+    """cdna guide rule 26: force the running-max jump.  One late key matches every query strongly,
+    so the max jumps by ~hundreds at a chosen unit in some wave's stream; earlier mass must be
+    rescaled away exactly once."""
+    rng = np.random.default_rng(11)
+    T, H = 700, 2
+    q = rng.standard_normal((T, 128), dtype=np.float32)
+    k = rng.standard_normal((T, 128), dtype=np.float32)
+    v = rng.standard_normal((T, 128), dtype=np.float32)
+    for spike in (5, 200, 333, 650):
+        k2 = k.copy()
+        k2[spike, :64] = 6.0 * np.sign(q[spike + 3, :64])        # large score for most later queries
+        k2[spike, 64:] = -6.0 * np.sign(q[spike + 3, 64:])
+        out = cmhsa.attention_fwd(*_dev((q, k2, v), gpu_device), H).cpu().numpy()
+        want = oracle.naive_attention_f64(q, k2, v, H)
+        assert np.isfinite(out).all()
+        assert np.abs(out - want).max() <= TOL
+    # extreme dynamic range: scores up to ~ +-100
+    out = cmhsa.attention_fwd(*_dev((4 * q, 4 * k, v), gpu_device), H).cpu().numpy()
+    assert np.abs(out - oracle.naive_attention_f64(4 * q, 4 * k, v, H)).max() <= TOL
+
+
+def test_every_output_element_is_written(gpu_device):
+    # the torch binding hands the kernel torch::empty memory (CMHSA.cu:498): poison it first
+    torch.manual_seed(3)
+    for T in (1, 33, 100):
+        Q, K, V = (torch.rand(T, 768, device=gpu_device) for _ in range(3))
+        out = torch.full((T, 768), float("nan"), device=gpu_device)
+        cmhsa.attention_fwd(Q, K, V, 12, out=out)
+        assert torch.isfinite(out).all()
+        assert torch.allclose(out[0], V[0], atol=1e-6)            # row 0 sees key 0 only
+
+
+def test_module_matches_reference_golden_on_gpu(gpu_device):
+    from test_host import _load_module
+
+    mod, x = _load_module(CUSTOM, gpu_device)
+    with torch.no_grad():
+        y = mod(x).squeeze(0).cpu().numpy()
+    z = np.load(cases.golden_path("module_t40_d768"))
+    assert np.abs(y - z["expected"]).max() <= TOL
+    # and custom vs naive backend on the same device, same weights
+    mod_n, _ = _load_module(NAIVE, gpu_device)
+    with torch.no_grad():
+        assert (mod(x) - mod_n(x)).abs().max().item() <= TOL
+
+
+def test_error_behaviour_of_the_op(gpu_device):
+    import causal_multihead_self_attention  # noqa: F401
+
+    op = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_torch
+    x = torch.rand(8, 768, device=gpu_device)
+    with pytest.raises(RuntimeError, match="float32"):
+        op(Q=x.double(), K=x.double(), V=x.double(), num_heads=12)
+    with pytest.raises(RuntimeError, match="Head dimension must be 64"):
+        op(Q=x, K=x, V=x, num_heads=6)
+    with pytest.raises(RuntimeError, match="evenly divisible"):
+        op(Q=x, K=x, V=x, num_heads=5)
+    with pytest.raises(RuntimeError, match="same sequence length"):
+        op(Q=x, K=x[:4], V=x, num_heads=12)
+    with pytest.raises(RuntimeError, match="stride"):
+        op(Q=x.t().contiguous().t(), K=x, V=x, num_heads=12)
+    empty = op(Q=x[:0], K=x[:0], V=x[:0], num_heads=12)
+    assert empty.shape == (0, 768)
+
+
+def test_non_default_stream(gpu_device):
+    torch.manual_seed(4)
+    Q, K, V = (torch.randn(257, 768, device=gpu_device) for _ in range(3))
+    ref = cmhsa.attention_fwd(Q, K, V, 12)
+    s = torch.cuda.Stream(device=gpu_device)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        got = cmhsa.attention_fwd(Q, K, V, 12)
+    s.synchronize()
+    assert torch.equal(ref, got)
+
+
+def test_full_size_properties_config5_shape(gpu_device):
+    """BASELINE.json config 5 geometry per GPU under 8-way head sharding is (B=32, T=4096, H=2); here a
+    (B=4, T=4096, H=16) slab keeps the test short.  Size-independent checks: constant-V invariance,
+    row 0 == V[0], linearity in V, and f64-oracle agreement on sampled (batch, head) pairs."""
+    torch.manual_seed(5)
+    B, T, H = 4, 4096, 16
+    d = 64 * H
+    Q = torch.randn(B, T, d, device=gpu_device)
+    K = torch.randn(B, T, d, device=gpu_device)
+    V1 = torch.randn(B, T, d, device=gpu_device)
+    V2 = torch.randn(B, T, d, device=gpu_device)
+    o1 = cmhsa.attention_fwd(Q, K, V1, H)
+    o2 = cmhsa.attention_fwd(Q, K, V2, H)
+    o12 = cmhsa.attention_fwd(Q, K, 0.5 * V1 - 2.0 * V2, H)
+    assert torch.isfinite(o1).all()
+    assert (o12 - (0.5 * o1 - 2.0 * o2)).abs().max().item() <= TOL              # linear in V
+    assert torch.allclose(o1[:, 0], V1[:, 0], atol=1e-6)                          # first row
+    const = torch.arange(d, device=gpu_device, dtype=torch.float32).expand(B, T, d).contiguous()
+    oc = cmhsa.attention_fwd(Q, K, const, H)
+    assert (oc - const).abs().max().item() <= 1e-3 * d / 1024 + 2e-4              # softmax rows sum to 1
+    for b, h in ((0, 0), (3, 15), (2, 7)):
+        sl = slice(64 * h, 64 * h + 64)
+        want = oracle.naive_attention_f64(Q[b, :, sl].cpu().numpy(), K[b, :, sl].cpu().numpy(),
+                                          V1[b, :, sl].cpu().numpy(), 1)
+        assert np.abs(o1[b, :, sl].cpu().numpy() - want).max() <= TOL
