@@ -30,17 +30,19 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHeadDim = 64;            // CMHSA.cu:432
 constexpr int kQBlock = 32;             // query rows per workgroup (one MFMA N-tile)
 constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
-constexpr int kWaves = 4;               // split-KV ways inside a workgroup
+constexpr int kWaves = 8;               // split-KV ways inside a workgroup; two waves per SIMD
 constexpr int kThreads = kWaves * 64;
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
-constexpr int kWaveLdsFloats = 4 * kUnitFloats;           // K[2] + V[2] = 32 KiB per wave
+constexpr int kWaveLdsFloats = 2 * kUnitFloats;           // K + V = 16 KiB per wave
 constexpr int kLdsBytes = kWaves * kWaveLdsFloats * 4;    // 128 KiB per workgroup
 constexpr int kCombStride = 33;                           // O^T merge image: [64 d][32 q + 1 pad]
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
+constexpr float kRescaleThreshold = 16.f;                 // lazy rescale: keep the old max while it is within 2^16
 
 struct Params {
     const float *q, *k, *v;
@@ -68,24 +70,22 @@ __device__ __forceinline__ float xhalf_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// Buffer descriptor over the <= 32 rows [row0, row0+32) of one head's 64-float column slab.  The
+// hardware range check returns 0 for rows >= N (their byte offset is >= num_records), so ragged
+// tails need no branches and masked keys can never inject NaN/garbage into 0 * V.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t unit_rsrc(const float *head_base, int64_t rs, int row0, int n_rows) {
+    const int valid = min(kKeyUnit, n_rows - row0);       // >= 1 for every unit the kernel touches
+    const int bytes = ((valid - 1) * (int)rs + kHeadDim) * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(head_base + (int64_t)row0 * rs), 0, bytes, 0x00020000);
+}
+
 // One 32-row x 64-float unit (8 KiB) global -> registers: lane l, step i reads the 16-B chunk
 // (l & 15) of row 4i + (l >> 4): 16 lanes cover one 256-B row, fully coalesced.
-__device__ __forceinline__ void load_unit(const float *__restrict__ base, int64_t rs, int row0, int n_rows,
-                                          int lane, f32x4 (&r)[8]) {
-    const int sub = lane >> 4, chunk = lane & 15;
-    if (row0 + kKeyUnit <= n_rows) {
+// voff = per-lane byte offset of (row l>>4, chunk l&15); step = 4 rows in bytes.
+__device__ __forceinline__ void load_unit(__amdgpu_buffer_rsrc_t rsrc, int voff, int step, f32x4 (&r)[8]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            r[i] = *reinterpret_cast<const f32x4 *>(base + (int64_t)(row0 + 4 * i + sub) * rs + chunk * 4);
-    } else {   // ragged last unit: rows >= N are zero-filled (they are masked, but 0 * NaN must not arise)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = row0 + 4 * i + sub;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if (row < n_rows) z = *reinterpret_cast<const f32x4 *>(base + (int64_t)row * rs + chunk * 4);
-            r[i] = z;
-        }
-    }
+    for (int i = 0; i < 8; ++i)
+        r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * step, 0, 0));
 }
 
 // registers -> this wave's LDS unit.  K is XOR-swizzled per row (16-B chunk c of row r lives at
@@ -101,7 +101,7 @@ __device__ __forceinline__ void store_unit(float *lds, int lane, const f32x4 (&r
     }
 }
 
-__global__ __launch_bounds__(kThreads) void cmhsa_fwd_kernel(Params p) {
+__global__ __launch_bounds__(kThreads, 2) void cmhsa_fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int lane = threadIdx.x & 63;
@@ -127,11 +127,12 @@ __global__ __launch_bounds__(kThreads) void cmhsa_fwd_kernel(Params p) {
     const int q0 = qb * kQBlock;
     const int n_units = qb + 1;      // causal early exit: units past the diagonal are never touched (CMHSA.cu:133-136)
 
-    const float *__restrict__ qg = p.q + b * p.q_bs + (int64_t)h * kHeadDim;
-    const float *__restrict__ kg = p.k + b * p.k_bs + (int64_t)h * kHeadDim;
-    const float *__restrict__ vg = p.v + b * p.v_bs + (int64_t)h * kHeadDim;
+    const float *qg = p.q + b * p.q_bs + (int64_t)h * kHeadDim;
+    const float *kg = p.k + b * p.k_bs + (int64_t)h * kHeadDim;
+    const float *vg = p.v + b * p.v_bs + (int64_t)h * kHeadDim;
 
-    float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: K0 K1 V0 V1
+    float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: K | V
+    float *kb = wlds, *vb = wlds + kUnitFloats;
 
     f32x16 o0 = {0}, o1 = {0};       // O^T accumulators: d = acc_row(r) + 4*half (+32 for o1), query = l31
     float m_run = -INFINITY;         // running max (log2 domain), same in both lane halves
@@ -141,31 +142,34 @@ __global__ __launch_bounds__(kThreads) void cmhsa_fwd_kernel(Params p) {
         // ---- Q^T fragment: B operand of S^T = K Q^T.  k-step s = 4c + j uses d = 8c + 4*half + j ----
         float qf[32];
         {
-            const int qrow = q0 + l31;
-            const float *qp = qg + (int64_t)qrow * p.q_rs + 4 * half;
+            const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, q0, N);
+            const int qoff = (l31 * (int)p.q_rs + 4 * half) * 4;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                if (qrow < N) t = *reinterpret_cast<const f32x4 *>(qp + 8 * c);
+                const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 32 * c, 0, 0));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) qf[4 * c + j] = t[j] * kScaleLog2;
             }
         }
 
-        f32x4 kst[8], vst[8];        // register staging of the next unit
-        load_unit(kg, p.k_rs, wave * kKeyUnit, N, lane, kst);
-        load_unit(vg, p.v_rs, wave * kKeyUnit, N, lane, vst);
-        store_unit<true>(wlds, lane, kst);
-        store_unit<false>(wlds + 2 * kUnitFloats, lane, vst);
-        if (wave + kWaves < n_units) {
-            load_unit(kg, p.k_rs, (wave + kWaves) * kKeyUnit, N, lane, kst);
-            load_unit(vg, p.v_rs, (wave + kWaves) * kKeyUnit, N, lane, vst);
-        }
-        int cur = 0;
+        const int sub = lane >> 4, chunk = lane & 15;
+        const int koff = (sub * (int)p.k_rs + chunk * 4) * 4, kstep = 16 * (int)p.k_rs;
+        const int voff = (sub * (int)p.v_rs + chunk * 4) * 4, vstep = 16 * (int)p.v_rs;
+
+        f32x4 kst[8], vst[8];        // register staging of the next unit (prefetched one unit ahead)
+        load_unit(unit_rsrc(kg, p.k_rs, wave * kKeyUnit, N), koff, kstep, kst);
+        load_unit(unit_rsrc(vg, p.v_rs, wave * kKeyUnit, N), voff, vstep, vst);
 
         for (int u = wave; u < n_units; u += kWaves) {
-            const float *kb = wlds + cur * kUnitFloats;
-            const float *vb = wlds + (2 + cur) * kUnitFloats;
+            // ---- staged registers -> LDS (the previous unit's reads are all issued: in-order LDS queue) ----
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            store_unit<true>(kb, lane, kst);
+            store_unit<false>(vb, lane, vst);
+            if (u + kWaves < n_units) {
+                load_unit(unit_rsrc(kg, p.k_rs, (u + kWaves) * kKeyUnit, N), koff, kstep, kst);
+                load_unit(unit_rsrc(vg, p.v_rs, (u + kWaves) * kKeyUnit, N), voff, vstep, vst);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
@@ -190,36 +194,31 @@ __global__ __launch_bounds__(kThreads) void cmhsa_fwd_kernel(Params p) {
                     if (acc_row(r) + 4 * half > l31) s[r] = -INFINITY;
             }
 
-            // ---- online softmax, log2 domain; every processed unit has >=1 unmasked key per row ----
+            // ---- online softmax, log2 domain; every processed unit has >=1 unmasked key per row.
+            //      Lazy rescale: O and l are only rescaled when some row's max grew by more than
+            //      2^kRescaleThreshold (fp32 has the exponent range; precision is unaffected). ----
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
             mx = xhalf_max(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 0 on the first unit (m_run = -inf)
+            if (!__all(mx <= m_run + kRescaleThreshold)) {       // always taken on the first unit (m_run = -inf)
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+            }
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+                s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
                 psum += s[r];
             }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
-            }
-
-            // ---- next unit: staged registers -> the other LDS buffer, then refill the registers ----
-            if (u + kWaves < n_units) {
-                store_unit<true>(wlds + (cur ^ 1) * kUnitFloats, lane, kst);
-                store_unit<false>(wlds + (2 + (cur ^ 1)) * kUnitFloats, lane, vst);
-                if (u + 2 * kWaves < n_units) {
-                    load_unit(kg, p.k_rs, (u + 2 * kWaves) * kKeyUnit, N, lane, kst);
-                    load_unit(vg, p.v_rs, (u + 2 * kWaves) * kKeyUnit, N, lane, vst);
-                }
-            }
+            l_run += psum;
 
             // ---- O^T[d][query] += sum_key V[key][d] * P[query][key] : 32 MFMAs.
             //      k-step r pairs keys acc_row(r) (lanes 0-31) and acc_row(r)+4 (lanes 32-63), which is
@@ -230,12 +229,11 @@ __global__ __launch_bounds__(kThreads) void cmhsa_fwd_kernel(Params p) {
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[r], o1, 0, 0, 0);
             }
-            cur ^= 1;
         }
         l_run = xhalf_sum(l_run);
     }
 
-    // ---- merge the 4 split-KV partials.  Each wave first writes into ITS OWN region, so no
+    // ---- merge the split-KV partials.  Each wave first writes into ITS OWN region, so no
     //      barrier is needed before the writes; idle waves publish (m=-inf, l=0, O=0). ----
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -255,11 +253,11 @@ __global__ __launch_bounds__(kThreads) void cmhsa_fwd_kernel(Params p) {
     }
     __syncthreads();
 
-    // thread -> (query = wave + 4i, d = lane): a wave stores one whole 256-B output row per step
+    // thread -> (query = wave + 8i, d = lane): a wave stores one whole 256-B output row per step
     float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int q = wave + 4 * i;
+    for (int i = 0; i < kQBlock / kWaves; ++i) {
+        const int q = wave + kWaves * i;
         if (q0 + q >= N) break;                              // wave-uniform
         float mw[kWaves], lw[kWaves];
         float m_tot = -INFINITY;

@@ -1,0 +1,52 @@
+// cmhsa_bench.cpp -- native (no Python, no torch) driver of the C ABI in include/cmhsa.h.
+// Used for rocprofv3 counter passes (the program after `--` must not re-exec) and for quick
+// A/B timing of kernel variants.  Build:  make -C tools     Run:  tools/cmhsa_bench B H T [steps] [warmup]
+// Inputs are U[0,1) (the reference test's distribution, test_torch_extension.py:16-18) laid out as
+// QKV column slices of one (B, T, 3*d_model) buffer, exactly what the model hands over.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "cmhsa.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 1, H = argc > 2 ? atoi(argv[2]) : 12, T = argc > 3 ? atoi(argv[3]) : 1024;
+    const int steps = argc > 4 ? atoi(argv[4]) : 200, warmup = argc > 5 ? atoi(argv[5]) : 20;
+    const int64_t d = 64LL * H, rs = 3 * d, n_in = (int64_t)B * T * rs, n_out = (int64_t)B * T * d;
+    std::vector<float> h(n_in);
+    std::mt19937 rng(1234);
+    std::uniform_real_distribution<float> u(0.f, 1.f);
+    for (auto &x : h) x = u(rng);
+    float *qkv = nullptr, *o = nullptr;
+    CHECK(hipMalloc(&qkv, n_in * sizeof(float)));
+    CHECK(hipMalloc(&o, n_out * sizeof(float)));
+    CHECK(hipMemcpy(qkv, h.data(), n_in * sizeof(float), hipMemcpyHostToDevice));
+    hipStream_t s;
+    CHECK(hipStreamCreate(&s));
+    auto run = [&]() {
+        return cmhsa_fp32_fwd(qkv, qkv + d, qkv + 2 * d, o, rs, rs, rs, d, (int64_t)T * rs, (int64_t)T * rs, (int64_t)T * rs,
+                              (int64_t)T * d, B, T, H, 64, s);
+    };
+    for (int i = 0; i < warmup; ++i) if (int rc = run()) { fprintf(stderr, "cmhsa: %s\n", cmhsa_status_string(rc)); return 1; }
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipStreamSynchronize(s));
+    CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < steps; ++i) run();
+    CHECK(hipEventRecord(e1, s));
+    CHECK(hipStreamSynchronize(s));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = cmhsa_algorithmic_flops(B, T, H, 64), us = ms * 1e3 / steps;
+    std::vector<float> ho(64);
+    CHECK(hipMemcpy(ho.data(), o, 64 * sizeof(float), hipMemcpyDeviceToHost));
+    printf("{\"B\": %d, \"H\": %d, \"T\": %d, \"steps\": %d, \"us_per_launch\": %.3f, \"tflops\": %.3f, \"frac_of_157.3\": %.4f, \"o00\": %.6f}\n",
+           B, H, T, steps, us, flops / us / 1e6, flops / us / 1e6 / 157.3, ho[0]);
+    return 0;
+}
