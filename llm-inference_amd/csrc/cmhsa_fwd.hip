@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <cstdlib>
 
 #include "cmhsa.h"
 
@@ -30,19 +31,39 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHeadDim = 64;            // CMHSA.cu:432
 constexpr int kQBlock = 32;             // query rows per workgroup (one MFMA N-tile)
 constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
-constexpr int kWaves = 8;               // split-KV ways inside a workgroup; two waves per SIMD
-constexpr int kThreads = kWaves * 64;
+// split-KV ways inside a workgroup = waves per workgroup (template parameter kWaves):
+//   8 -> one 128-KiB workgroup per CU (two of its waves per SIMD): shortest chain per query block
+//   4 -> two 64-KiB workgroups per CU: prologue/merge of one overlaps the main loop of the other
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
 constexpr int kWaveLdsFloats = 2 * kUnitFloats;           // K + V = 16 KiB per wave
-constexpr int kLdsBytes = kWaves * kWaveLdsFloats * 4;    // 128 KiB per workgroup
+constexpr int lds_bytes(int waves) { return waves * kWaveLdsFloats * 4; }
 constexpr int kCombStride = 33;                           // O^T merge image: [64 d][32 q + 1 pad]
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
 constexpr float kRescaleThreshold = 16.f;                 // lazy rescale: keep the old max while it is within 2^16
+
+// Diagnostic build only (-DCMHSA_STAMPS, tools/Makefile target cmhsa_bench_stamps): s_memtime stamps of
+// one workgroup's phases go to a buffer of their own; no output value depends on them.  The shipped
+// library is built without it and executes no stamp.
+#ifdef CMHSA_STAMPS
+__device__ unsigned long long *g_stamp_buf = nullptr;
+__device__ int g_stamp_block = 0;
+#define STAMP(slot)                                                                              \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (stamp_on && (slot) < 128) stamp_ptr[(slot)] = t_;                                    \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
 
 struct Params {
     const float *q, *k, *v;
@@ -73,9 +94,12 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 // Buffer descriptor over the <= 32 rows [row0, row0+32) of one head's 64-float column slab.  The
 // hardware range check returns 0 for rows >= N (their byte offset is >= num_records), so ragged
 // tails need no branches and masked keys can never inject NaN/garbage into 0 * V.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t unit_rsrc(const float *head_base, int64_t rs, int row0, int n_rows) {
+// `enable` = false gives num_records = 0: every load through it returns 0 and touches no memory, which
+// keeps the software pipeline branch-free past the last unit.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t unit_rsrc(const float *head_base, int64_t rs, int row0, int n_rows,
+                                                            bool enable = true) {
     const int valid = min(kKeyUnit, n_rows - row0);       // >= 1 for every unit the kernel touches
-    const int bytes = ((valid - 1) * (int)rs + kHeadDim) * 4;
+    const int bytes = enable ? ((valid - 1) * (int)rs + kHeadDim) * 4 : 0;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(head_base + (int64_t)row0 * rs), 0, bytes, 0x00020000);
 }
 
@@ -101,13 +125,20 @@ __device__ __forceinline__ void store_unit(float *lds, int lane, const f32x4 (&r
     }
 }
 
-__global__ __launch_bounds__(kThreads, 2) void cmhsa_fwd_kernel(Params p) {
+template <int kWaves>
+__global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;      // which k-slot of the MFMA operand this lane feeds
-    const int l31 = lane & 31;       // query (B/C column) or key / d (A row) index of this lane
+#ifdef CMHSA_STAMPS
+    const bool stamp_on = g_stamp_buf != nullptr && (int)blockIdx.x == g_stamp_block && lane == 0;
+    unsigned long long *stamp_ptr = g_stamp_buf + wave * 128;
+    int stamp_i = 4;
+    STAMP(0);
+#endif
+    const int l31 = lane & 31;       // query (B/C column) or key / d-pair (A row) index of this lane
 
     // ---- blockIdx -> (batch*head, query block); heaviest query blocks first ----
     int bh, qb;
@@ -131,16 +162,39 @@ __global__ __launch_bounds__(kThreads, 2) void cmhsa_fwd_kernel(Params p) {
     const float *kg = p.k + b * p.k_bs + (int64_t)h * kHeadDim;
     const float *vg = p.v + b * p.v_bs + (int64_t)h * kHeadDim;
 
-    float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: K | V
-    float *kb = wlds, *vb = wlds + kUnitFloats;
+    float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: K[0] | K[1] (double-buffered)
 
-    f32x16 o0 = {0}, o1 = {0};       // O^T accumulators: d = acc_row(r) + 4*half (+32 for o1), query = l31
+    // O^T accumulators.  MFMA row i of o0 / o1 is d = 2i / 2i+1, so that one dwordx2 per lane fetches both
+    // A operands of a PV k-step and each half-wave reads one whole contiguous 256-B V row:
+    //   o0[r] <-> d = 2*(acc_row(r) + 4*half),  o1[r] <-> d + 1,  query = l31.
+    f32x16 o0 = {0}, o1 = {0};
     float m_run = -INFINITY;         // running max (log2 domain), same in both lane halves
     float l_run = 0.f;               // running sum over THIS lane half's keys only (merged at the end)
 
     if (wave < n_units) {
-        // ---- Q^T fragment: B operand of S^T = K Q^T.  k-step s = 4c + j uses d = 8c + 4*half + j ----
-        float qf[32];
+        // per-lane byte offsets inside a unit
+        const int sub = lane >> 4, chunk = lane & 15;
+        const int koff = (sub * (int)p.k_rs + chunk * 4) * 4, kstep = 16 * (int)p.k_rs;   // K: coalesced rows -> LDS
+        const int vrs4 = (int)p.v_rs * 4;
+        const int voff = half * 4 * vrs4 + l31 * 8;                                       // V: straight into MFMA layout
+        const float *krow0 = wlds + l31 * kHeadDim;
+        const int sw = l31 & 15;
+        auto kfrag = [&](int buf, int c) {
+            return *reinterpret_cast<const f32x4 *>(krow0 + buf * kUnitFloats + (((2 * c + half) ^ sw) << 2));
+        };
+
+        // ---- prologue: K(u0) -> regs -> LDS[0]; Q -> regs; K(u1) prefetch.  All per-lane load offsets are
+        //      computed once: VALU instructions are NOT free beside fp32 MFMAs (they share the SIMD's fp32
+        //      datapath: measured cost = sum of both), so the main loop carries as few as possible. ----
+        int koffs[8], voffs[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) koffs[i] = koff + i * kstep;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) voffs[r] = voff + acc_row(r) * vrs4;
+        f32x4 kst[8];                // K staging registers (always one unit ahead of LDS)
+        f32x2 vreg[16];              // V of the current unit, MFMA A-operand layout: [k-step r] = {d even, d odd}
+        load_unit(unit_rsrc(kg, p.k_rs, wave * kKeyUnit, N), koff, kstep, kst);
+        float qf[32];                // Q^T fragment: B operand of S^T = K Q^T; k-step 4c+j uses d = 8c + 4*half + j
         {
             const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, q0, N);
             const int qoff = (l31 * (int)p.q_rs + 4 * half) * 4;
@@ -151,42 +205,41 @@ __global__ __launch_bounds__(kThreads, 2) void cmhsa_fwd_kernel(Params p) {
                 for (int j = 0; j < 4; ++j) qf[4 * c + j] = t[j] * kScaleLog2;
             }
         }
-
-        const int sub = lane >> 4, chunk = lane & 15;
-        const int koff = (sub * (int)p.k_rs + chunk * 4) * 4, kstep = 16 * (int)p.k_rs;
-        const int voff = (sub * (int)p.v_rs + chunk * 4) * 4, vstep = 16 * (int)p.v_rs;
-
-        f32x4 kst[8], vst[8];        // register staging of the next unit (prefetched one unit ahead)
-        load_unit(unit_rsrc(kg, p.k_rs, wave * kKeyUnit, N), koff, kstep, kst);
-        load_unit(unit_rsrc(vg, p.v_rs, wave * kKeyUnit, N), voff, vstep, vst);
+        store_unit<true>(wlds, lane, kst);
+        load_unit(unit_rsrc(kg, p.k_rs, (wave + kWaves) * kKeyUnit, N, wave + kWaves < n_units), koff, kstep, kst);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 kcur = kfrag(0, 0), knext = kfrag(0, 1);
+        int cur = 0;
+        STAMP(1);
 
         for (int u = wave; u < n_units; u += kWaves) {
-            // ---- staged registers -> LDS (the previous unit's reads are all issued: in-order LDS queue) ----
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            store_unit<true>(kb, lane, kst);
-            store_unit<false>(vb, lane, vst);
-            if (u + kWaves < n_units) {
-                load_unit(unit_rsrc(kg, p.k_rs, (u + kWaves) * kKeyUnit, N), koff, kstep, kst);
-                load_unit(unit_rsrc(vg, p.v_rs, (u + kWaves) * kKeyUnit, N), voff, vstep, vst);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-
-            // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] : 32 MFMAs ----
+            const bool has_next = u + kWaves < n_units;
+#ifdef CMHSA_STAMPS
+            STAMP(stamp_i);
+#endif
+            // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] : 32 chained MFMAs.  K fragments are read
+            //      two steps (512 MFMA cycles) ahead. ----
+            //      V(u) goes straight into its MFMA operand registers, two loads per step: memory instructions
+            //      between MFMAs are free, and the loads have the rest of the chain + the softmax to land.
+            const __amdgpu_buffer_rsrc_t vsrc = unit_rsrc(vg, p.v_rs, u * kKeyUnit, N);
             f32x16 s = {0};
-            {
-                const float *krow = kb + l31 * kHeadDim;
-                const int sw = l31 & 15;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const f32x4 kk = *reinterpret_cast<const f32x4 *>(krow + (((2 * c + half) ^ sw) << 2));
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 kk = kcur;
+                kcur = knext;
+                if (c + 2 < 8) knext = kfrag(cur, c + 2);
+                vreg[2 * c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc, voffs[2 * c], 0, 0));
+                vreg[2 * c + 1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc, voffs[2 * c + 1], 0, 0));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[j], qf[4 * c + j], s, 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j)
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[j], qf[4 * c + j], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-
+#ifdef CMHSA_STAMPS
+            STAMP(stamp_i + 1);
+#endif
             // ---- causal mask: only the diagonal unit has key > query pairs (CMHSA.cu:228, :249) ----
             if (u == qb) {
 #pragma unroll
@@ -212,26 +265,62 @@ __global__ __launch_bounds__(kThreads, 2) void cmhsa_fwd_kernel(Params p) {
                     o1[r] *= alpha;
                 }
             }
-            float psum = 0.f;
+            f32x2 psum2 = {0.f, 0.f};                 // packed fp32 ops: two elements per VALU issue slot
+            const f32x2 m2 = {m_run, m_run};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 t = {s[r], s[r + 1]};
+                t -= m2;
+                t[0] = __builtin_amdgcn_exp2f(t[0]);
+                t[1] = __builtin_amdgcn_exp2f(t[1]);
+                psum2 += t;
+                s[r] = t[0];
+                s[r + 1] = t[1];
+            }
+            l_run += psum2[0] + psum2[1];
+#ifdef CMHSA_STAMPS
+            STAMP(stamp_i + 2);
+#endif
+            // ---- O^T[d][query] += sum_key V[key][d] * P[query][key] : 32 MFMAs, all operands in registers.
+            //      k-step r pairs keys acc_row(r) (lanes 0-31) and acc_row(r)+4 (lanes 32-63), which is exactly
+            //      where accumulator register r of S^T holds them: P feeds the B operand as it stands.
+            //      Interleaved with the chain (program order = issue order, one item per MFMA pair):
+            //        steps 0-7  : staged K(u+1) registers -> the other LDS buffer
+            //        steps 8-15 : K(u+2) global -> staging registers;  steps 13,14: first K(u+1) fragments ----
+            //      Everything is unconditional (past the last unit the descriptors have zero records and the
+            //      LDS traffic goes to the idle buffer), so the chain stays one basic block.
+            const __amdgpu_buffer_rsrc_t ksrc2 = unit_rsrc(kg, p.k_rs, (u + 2 * kWaves) * kKeyUnit, N, u + 2 * kWaves < n_units);
+            float *knew = wlds + (cur ^ 1) * kUnitFloats;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
-                psum += s[r];
+                if (r < 8) {
+                    const int row = 4 * r + sub;
+                    *reinterpret_cast<f32x4 *>(knew + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = kst[r];
+                } else {
+                    kst[r - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ksrc2, koffs[r - 8], 0, 0));
+                    if (r == 13) kcur = kfrag(cur ^ 1, 0);
+                    if (r == 14) knext = kfrag(cur ^ 1, 1);
+                }
+                if (r == 8) {   // all K(u+1) stores are queued: order them before this wave's later LDS reads
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r][0], s[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r][1], s[r], o1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            l_run += psum;
-
-            // ---- O^T[d][query] += sum_key V[key][d] * P[query][key] : 32 MFMAs.
-            //      k-step r pairs keys acc_row(r) (lanes 0-31) and acc_row(r)+4 (lanes 32-63), which is
-            //      exactly where accumulator register r of S^T holds them: P feeds the B operand as is.
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float *vrow = vb + (acc_row(r) + 4 * half) * kHeadDim + l31;
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[r], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[r], o1, 0, 0, 0);
-            }
+#ifdef CMHSA_STAMPS
+            STAMP(stamp_i + 3);
+            stamp_i += 4;
+#endif
+            cur ^= 1;
         }
         l_run = xhalf_sum(l_run);
     }
+#ifdef CMHSA_STAMPS
+    STAMP(2);
+#endif
 
     // ---- merge the split-KV partials.  Each wave first writes into ITS OWN region, so no
     //      barrier is needed before the writes; idle waves publish (m=-inf, l=0, O=0). ----
@@ -242,9 +331,9 @@ __global__ __launch_bounds__(kThreads, 2) void cmhsa_fwd_kernel(Params p) {
         float *ml = wlds + kHeadDim * kCombStride;          // m[32], l[32]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int d = acc_row(r) + 4 * half;
+            const int d = 2 * (acc_row(r) + 4 * half);
             ob[d * kCombStride + l31] = o0[r];
-            ob[(d + 32) * kCombStride + l31] = o1[r];
+            ob[(d + 1) * kCombStride + l31] = o1[r];
         }
         if (lane < 32) {
             ml[lane] = m_run;
@@ -253,33 +342,80 @@ __global__ __launch_bounds__(kThreads, 2) void cmhsa_fwd_kernel(Params p) {
     }
     __syncthreads();
 
-    // thread -> (query = wave + 8i, d = lane): a wave stores one whole 256-B output row per step
+    // thread -> (query = wave + kWaves*i, d = lane): a wave stores one whole 256-B output row per step.
+    // All rows of a wave are processed together (no early exit) so their LDS reads overlap.
     float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
+    constexpr int kRows = kQBlock / kWaves;
+    float mw[kRows][kWaves], lw[kRows][kWaves], ow[kRows][kWaves];
 #pragma unroll
-    for (int i = 0; i < kQBlock / kWaves; ++i) {
+    for (int i = 0; i < kRows; ++i) {
         const int q = wave + kWaves * i;
-        if (q0 + q >= N) break;                              // wave-uniform
-        float mw[kWaves], lw[kWaves];
-        float m_tot = -INFINITY;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
-            const float *ml = lds + w * kWaveLdsFloats + kHeadDim * kCombStride;
-            mw[w] = ml[q];
-            lw[w] = ml[32 + q];
-            m_tot = fmaxf(m_tot, mw[w]);
+            const float *base = lds + w * kWaveLdsFloats;
+            mw[i][w] = base[kHeadDim * kCombStride + q];
+            lw[i][w] = base[kHeadDim * kCombStride + 32 + q];
+            ow[i][w] = base[lane * kCombStride + q];
         }
+    }
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+        const int q = wave + kWaves * i;
+        float m_tot = mw[i][0];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) m_tot = fmaxf(m_tot, mw[i][w]);
         float acc = 0.f, l_tot = 0.f;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
-            const float f = __builtin_amdgcn_exp2f(mw[w] - m_tot);
-            l_tot += lw[w] * f;
-            acc += lds[w * kWaveLdsFloats + lane * kCombStride + q] * f;
+            const float f = __builtin_amdgcn_exp2f(mw[i][w] - m_tot);
+            l_tot += lw[i][w] * f;
+            acc += ow[i][w] * f;
         }
-        og[(int64_t)(q0 + q) * p.o_rs + lane] = acc / l_tot;
+        if (q0 + q < N) og[(int64_t)(q0 + q) * p.o_rs + lane] = acc / l_tot;   // wave-uniform predicate
     }
+#ifdef CMHSA_STAMPS
+    STAMP(3);
+#endif
 }
 
-std::atomic<int> g_attr_set[64];     // per device: dynamic-LDS limit raised once, not per call
+std::atomic<int> g_attr_set[2][64];  // per variant and device: dynamic-LDS limit raised once, not per call
+
+template <int kWaves>
+hipError_t launch(const Params &p, int64_t blocks, void *stream) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kWaves == 8][dev] : nullptr;
+    if (!flag || !flag->load(std::memory_order_acquire)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kWaves));
+        if (e != hipSuccess) return e;
+        if (flag) flag->store(1, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(cmhsa_fwd_kernel<kWaves>, dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes(kWaves),
+                       static_cast<hipStream_t>(stream), p);
+    return hipSuccess;
+}
+
+// Waves per workgroup.  Measured on MI355X (tools/cmhsa_bench, profiles/): with more than ~2 workgroups per
+// CU the 4-wave form wins (two co-resident workgroups hide each other's prologue and merge: +7..12 %);
+// when the grid is between one and two rounds of 8-wave workgroups (BASELINE config 2: 384 blocks on 256
+// CUs) the 8-wave form wins because the longest query block's chain is half as long (-12 %).
+// CMHSA_WAVES=4|8 in the environment overrides (read once; for experiments).
+int choose_waves(int64_t blocks, int nqb) {
+    static const int forced = [] {
+        const char *e = getenv("CMHSA_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 4 || forced == 8) return forced;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    (void)nqb;
+    return (blocks > cus && blocks <= 5 * (int64_t)cus / 2) ? 8 : 4;
+}
 
 }  // namespace
 
@@ -298,6 +434,15 @@ const char *cmhsa_status_string(int status) {
 }
 
 int cmhsa_version(void) { return (1 << 16) | 0; }
+
+#ifdef CMHSA_STAMPS
+// diagnostic build only: buf = device buffer of 8 waves x 128 stamps, block = blockIdx.x to stamp
+int cmhsa_debug_set_stamps(unsigned long long *buf, int block) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_block), &block, sizeof(block));
+    return (int)e;
+}
+#endif
 
 double cmhsa_algorithmic_flops(int batch, int seq_len, int num_heads, int head_dim) {
     return 2.0 * batch * num_heads * head_dim * (double)seq_len * ((double)seq_len + 1.0);
@@ -322,16 +467,6 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     const int64_t blocks = bh * nqb;
     if (blocks > 0x7fffffffLL || bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
 
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64 || !g_attr_set[dev].load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        if (e != hipSuccess) return (int)e;
-        if (dev >= 0 && dev < 64) g_attr_set[dev].store(1, std::memory_order_release);
-    }
-
     Params p;
     p.q = q; p.k = k; p.v = v; p.o = o;
     p.q_rs = q_row_stride; p.k_rs = k_row_stride; p.v_rs = v_row_stride; p.o_rs = o_row_stride;
@@ -342,8 +477,9 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     p.nqb = (int)nqb;
     p.xcd_map = (bh % 8 == 0) ? 1 : 0;
 
-    hipLaunchKernelGGL(cmhsa_fwd_kernel, dim3((unsigned)blocks), dim3(kThreads), kLdsBytes,
-                       static_cast<hipStream_t>(stream), p);
+    const int waves = choose_waves(blocks, (int)nqb);
+    hipError_t e = waves == 8 ? launch<8>(p, blocks, stream) : launch<4>(p, blocks, stream);
+    if (e != hipSuccess) return (int)e;
     e = hipGetLastError();                 // launch-configuration errors only; no synchronisation (CMHSA.cu:450)
     return e == hipSuccess ? CMHSA_OK : (int)e;
 }

@@ -14,6 +14,10 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return 1; } } while (0)
 
+#ifdef CMHSA_STAMPS
+extern "C" int cmhsa_debug_set_stamps(unsigned long long *buf, int block);
+#endif
+
 int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 1, H = argc > 2 ? atoi(argv[2]) : 12, T = argc > 3 ? atoi(argv[3]) : 1024;
     const int steps = argc > 4 ? atoi(argv[4]) : 200, warmup = argc > 5 ? atoi(argv[5]) : 20;
@@ -48,5 +52,25 @@ int main(int argc, char **argv) {
     CHECK(hipMemcpy(ho.data(), o, 64 * sizeof(float), hipMemcpyDeviceToHost));
     printf("{\"B\": %d, \"H\": %d, \"T\": %d, \"steps\": %d, \"us_per_launch\": %.3f, \"tflops\": %.3f, \"frac_of_157.3\": %.4f, \"o00\": %.6f}\n",
            B, H, T, steps, us, flops / us / 1e6, flops / us / 1e6 / 157.3, ho[0]);
+#ifdef CMHSA_STAMPS
+    {   // one extra launch with stamps of workgroup `argv[6]` (default 0 = a heaviest query block)
+        unsigned long long *sb = nullptr;
+        CHECK(hipMalloc(&sb, 8 * 128 * sizeof(unsigned long long)));
+        CHECK(hipMemset(sb, 0, 8 * 128 * sizeof(unsigned long long)));
+        if (cmhsa_debug_set_stamps(sb, argc > 6 ? atoi(argv[6]) : 0)) return 1;
+        for (int i = 0; i < 3; ++i) run();
+        CHECK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs(8 * 128);
+        CHECK(hipMemcpy(hs.data(), sb, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        const unsigned long long t0 = hs[0];
+        for (int w = 0; w < 8; ++w) {
+            const unsigned long long *p = &hs[w * 128];
+            printf("wave %d: entry %lld  q_loaded %lld  loop_end %lld  done %lld | units (top, qk_start, qk_issued, pv_start):\n", w,
+                   (long long)(p[0] - t0), (long long)(p[1] - t0), (long long)(p[2] - t0), (long long)(p[3] - t0));
+            for (int i = 4; i + 3 < 128 && p[i]; i += 4)
+                printf("    %lld %lld %lld %lld\n", (long long)(p[i] - t0), (long long)(p[i + 1] - t0), (long long)(p[i + 2] - t0), (long long)(p[i + 3] - t0));
+        }
+    }
+#endif
     return 0;
 }
