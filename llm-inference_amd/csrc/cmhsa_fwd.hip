@@ -42,7 +42,7 @@ constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
 //   4 -> two 64-KiB workgroups per CU: prologue/merge of one overlaps the main loop of the other
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
 constexpr int kWaveLdsFloats = 2 * kUnitFloats;           // K + V = 16 KiB per wave
-constexpr int lds_bytes(int waves) { return waves * kWaveLdsFloats * 4; }
+constexpr int lds_bytes(int waves) { return (waves * kWaveLdsFloats + kUnitFloats) * 4; }   // + one shared, pre-scaled Q block
 constexpr int kCombStride = 33;                           // O^T merge image: [64 d][32 q + 1 pad]
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
 constexpr float kRescaleThreshold = 16.f;                 // lazy rescale: keep the old max while it is within 2^16
@@ -163,6 +163,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     const float *vg = p.v + b * p.v_bs + (int64_t)h * kHeadDim;
 
     float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: K[0] | K[1] (double-buffered)
+    float *qlds = lds + kWaves * kWaveLdsFloats; // shared: the query block, pre-scaled, K-style swizzle
+
+    // ---- the query block is fetched ONCE per workgroup (each wave 32/kWaves rows), scaled by
+    //      log2(e)/sqrt(64) and parked in LDS; every wave then reads its B-operand fragments from there ----
+    {
+        const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, q0, N);
+        constexpr int kRowsPerWave = kQBlock / kWaves;
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave / 4; ++i) {
+            const int row = wave * kRowsPerWave + 4 * i + (lane >> 4), chunk = lane & 15;
+            f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (row * (int)p.q_rs + chunk * 4) * 4, 0, 0));
+            t *= kScaleLog2;
+            *reinterpret_cast<f32x4 *>(qlds + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = t;
+        }
+    }
 
     // O^T accumulators.  MFMA row i of o0 / o1 is d = 2i / 2i+1, so that one dwordx2 per lane fetches both
     // A operands of a PV k-step and each half-wave reads one whole contiguous 256-B V row:
@@ -194,21 +209,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         f32x4 kst[8];                // K staging registers (always one unit ahead of LDS)
         f32x2 vreg[16];              // V of the current unit, MFMA A-operand layout: [k-step r] = {d even, d odd}
         load_unit(unit_rsrc(kg, p.k_rs, wave * kKeyUnit, N), koff, kstep, kst);
-        float qf[32];                // Q^T fragment: B operand of S^T = K Q^T; k-step 4c+j uses d = 8c + 4*half + j
-        {
-            const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, q0, N);
-            const int qoff = (l31 * (int)p.q_rs + 4 * half) * 4;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 32 * c, 0, 0));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) qf[4 * c + j] = t[j] * kScaleLog2;
-            }
-        }
         store_unit<true>(wlds, lane, kst);
         load_unit(unit_rsrc(kg, p.k_rs, (wave + kWaves) * kKeyUnit, N, wave + kWaves < n_units), koff, kstep, kst);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();             // Q block complete in LDS (every wave of the workgroup reaches this)
+        float qf[32];                // Q^T fragment: B operand of S^T = K Q^T; k-step 4c+j uses d = 8c + 4*half + j
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(qlds + l31 * kHeadDim + (((2 * c + half) ^ sw) << 2));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf[4 * c + j] = t[j];
+        }
         f32x4 kcur = kfrag(0, 0), knext = kfrag(0, 1);
         int cur = 0;
         STAMP(1);
@@ -317,61 +327,60 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             cur ^= 1;
         }
         l_run = xhalf_sum(l_run);
+    } else {
+        __syncthreads();             // pairs with the Q-block barrier of the active waves
     }
 #ifdef CMHSA_STAMPS
     STAMP(2);
 #endif
 
-    // ---- merge the split-KV partials.  Each wave first writes into ITS OWN region, so no
-    //      barrier is needed before the writes; idle waves publish (m=-inf, l=0, O=0). ----
+    // ---- merge the split-KV partials (idle waves carry m=-inf, l=0, O=0).
+    //      1. every wave publishes its (m, l);  2. every lane derives ITS wave's final weight
+    //      exp2(m_w - m_tot) / l_tot for its query, scales its O registers and writes them to its own
+    //      [64 d][33] image;  3. thread (query, d) adds the kWaves images and stores whole 256-B rows. ----
+    constexpr int kMlOff = kHeadDim * kCombStride;       // m[32] | l[32] sit behind the O image of each wave's own region
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (lane < 32) {
+        wlds[kMlOff + lane] = m_run;
+        wlds[kMlOff + 32 + lane] = l_run;
+    }
+    __syncthreads();
     {
-        float *ob = wlds;                                   // [64 d][33]
-        float *ml = wlds + kHeadDim * kCombStride;          // m[32], l[32]
+        float m_tot = -INFINITY, mw[kWaves], lw[kWaves];
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            mw[w] = lds[w * kWaveLdsFloats + kMlOff + l31];
+            lw[w] = lds[w * kWaveLdsFloats + kMlOff + 32 + l31];
+            m_tot = fmaxf(m_tot, mw[w]);
+        }
+        float l_tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) l_tot += lw[w] * __builtin_amdgcn_exp2f(mw[w] - m_tot);
+        const float f = __builtin_amdgcn_exp2f(m_run - m_tot) / l_tot;
+        float *ob = wlds;                                // this wave's own region: [64 d][33]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = 2 * (acc_row(r) + 4 * half);
-            ob[d * kCombStride + l31] = o0[r];
-            ob[(d + 1) * kCombStride + l31] = o1[r];
-        }
-        if (lane < 32) {
-            ml[lane] = m_run;
-            ml[32 + lane] = l_run;
+            ob[d * kCombStride + l31] = o0[r] * f;
+            ob[(d + 1) * kCombStride + l31] = o1[r] * f;
         }
     }
     __syncthreads();
-
-    // thread -> (query = wave + kWaves*i, d = lane): a wave stores one whole 256-B output row per step.
-    // All rows of a wave are processed together (no early exit) so their LDS reads overlap.
     float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
     constexpr int kRows = kQBlock / kWaves;
-    float mw[kRows][kWaves], lw[kRows][kWaves], ow[kRows][kWaves];
+    float acc[kRows];
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
         const int q = wave + kWaves * i;
+        acc[i] = 0.f;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const float *base = lds + w * kWaveLdsFloats;
-            mw[i][w] = base[kHeadDim * kCombStride + q];
-            lw[i][w] = base[kHeadDim * kCombStride + 32 + q];
-            ow[i][w] = base[lane * kCombStride + q];
-        }
+        for (int w = 0; w < kWaves; ++w) acc[i] += lds[w * kWaveLdsFloats + lane * kCombStride + q];
     }
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
         const int q = wave + kWaves * i;
-        float m_tot = mw[i][0];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) m_tot = fmaxf(m_tot, mw[i][w]);
-        float acc = 0.f, l_tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const float f = __builtin_amdgcn_exp2f(mw[i][w] - m_tot);
-            l_tot += lw[i][w] * f;
-            acc += ow[i][w] * f;
-        }
-        if (q0 + q < N) og[(int64_t)(q0 + q) * p.o_rs + lane] = acc / l_tot;   // wave-uniform predicate
+        if (q0 + q < N) og[(int64_t)(q0 + q) * p.o_rs + lane] = acc[i];      // wave-uniform predicate
     }
 #ifdef CMHSA_STAMPS
     STAMP(3);

@@ -110,9 +110,13 @@ def test_batched_rows_equal_single_calls(gpu_device):
     x = torch.randn(B, T, 3 * 64 * H, device=gpu_device)
     Q, K, V = x[..., :1024], x[..., 1024:2048], x[..., 2048:]
     out = cmhsa.attention_fwd(Q, K, V, H)
+    again = cmhsa.attention_fwd(Q, K, V, H)
+    assert torch.equal(out, again)                                  # same launch shape -> bitwise reproducible
     for b in range(B):
-        single = cmhsa.attention_fwd(Q[b], K[b], V[b], H)      # H = 16: plain block map
-        assert torch.equal(out[b], single)
+        # the split-KV width (4 or 8 waves) is chosen from the grid size, so a different batch size may
+        # sum in a different order: rows agree to rounding, not necessarily to the last bit
+        single = cmhsa.attention_fwd(Q[b], K[b], V[b], H)
+        assert (out[b] - single).abs().max().item() <= 2e-6
     want = oracle.naive_attention_f64(Q[1].cpu().numpy(), K[1].cpu().numpy(), V[1].cpu().numpy(), H)
     assert np.abs(out[1].cpu().numpy() - want).max() <= TOL
 
