@@ -42,7 +42,7 @@ constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
 //   4 -> two 64-KiB workgroups per CU: prologue/merge of one overlaps the main loop of the other
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
 constexpr int kWaveLdsFloats = 2 * kUnitFloats;           // K + V = 16 KiB per wave
-constexpr int lds_bytes(int waves) { return (waves * kWaveLdsFloats + kUnitFloats) * 4; }   // + one shared, pre-scaled Q block
+constexpr int lds_bytes(int waves) { return (waves * kWaveLdsFloats + 2 * kUnitFloats) * 4; }   // + two shared, pre-scaled Q blocks
 constexpr int kCombStride = 33;                           // O^T merge image: [64 d][32 q + 1 pad]
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
 constexpr float kRescaleThreshold = 16.f;                 // lazy rescale: keep the old max while it is within 2^16
@@ -53,6 +53,7 @@ constexpr float kRescaleThreshold = 16.f;                 // lazy rescale: keep 
 #ifdef CMHSA_STAMPS
 __device__ unsigned long long *g_stamp_buf = nullptr;
 __device__ int g_stamp_block = 0;
+__device__ unsigned long long *g_block_times = nullptr;   // [blockIdx][2]: s_memrealtime (100 MHz) at entry / exit
 #define STAMP(slot)                                                                              \
     do {                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -74,8 +75,28 @@ struct Params {
     int num_heads;                      // H
     int bh;                             // batch * H
     int nqb;                            // ceil(N / 32)
-    int xcd_map;                        // 1: blockIdx -> (bh, qb) keeps one (b,h) per XCD group
+    int xcd_map;                        // 1: blockIdx -> (bh, j) keeps one (b,h) per XCD group
+    // packing of query blocks into workgroups (pack_plan()):
+    int chain;                          // c: max units any wave processes = ceil(nqb / kWaves)
+    int n_paired;                       // R: query blocks 1..R units long are paired n <-> R+1-n
+    int n_alone;                        // nqb - R: the longest query blocks get a workgroup each
+    int wgs_per_bh;                     // n_alone + ceil(R / 2)
 };
+
+// Packing plan.  A query block with n units gets g(n) = ceil(n / c) waves, so that no wave runs more than
+// c = ceil(nqb / kWaves) units.  The R = min(nqb, c*(kWaves-1)) shortest blocks are paired n <-> R+1-n:
+// g(n) + g(R+1-n) == kWaves exactly (for R = c*(kWaves-1)), i.e. every paired workgroup has all its waves
+// busy with R+1 units in total; the nqb-R longest blocks each need all kWaves waves.  One round of
+// equally long workgroups instead of a tail of short ones that each hold a whole CU.
+struct PackPlan { int chain, n_paired, n_alone, wgs_per_bh; };
+inline PackPlan pack_plan(int nqb, int waves) {
+    PackPlan pl;
+    pl.chain = (nqb + waves - 1) / waves;
+    pl.n_paired = min(nqb, pl.chain * (waves - 1));
+    pl.n_alone = nqb - pl.n_paired;
+    pl.wgs_per_bh = pl.n_alone + (pl.n_paired + 1) / 2;
+    return pl;
+}
 
 // key/d index held by accumulator register r of a 32x32 MFMA result in lane half `half`
 // (C/D map of v_mfma_f32_32x32x2_f32: row = (r&3) + 8*(r>>2) + 4*half, col = lane&31).
@@ -137,46 +158,69 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     unsigned long long *stamp_ptr = g_stamp_buf + wave * 128;
     int stamp_i = 4;
     STAMP(0);
+    if (g_block_times && threadIdx.x == 0) g_block_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int l31 = lane & 31;       // query (B/C column) or key / d-pair (A row) index of this lane
 
-    // ---- blockIdx -> (batch*head, query block); heaviest query blocks first ----
-    int bh, qb;
+    // ---- blockIdx -> (batch*head, workgroup j of that head); heaviest workgroups first ----
+    int bh, j;
     {
         const int id = blockIdx.x;
         if (p.xcd_map) {             // blocks b and b+8 share an XCD: give each XCD group its own (b,h)
-            const int xcd = id & 7, j = id >> 3;
-            bh = (j / p.nqb) * 8 + xcd;
-            qb = p.nqb - 1 - (j % p.nqb);
+            const int xcd = id & 7, t = id >> 3;
+            bh = (t / p.wgs_per_bh) * 8 + xcd;
+            j = t % p.wgs_per_bh;
         } else {
             bh = id % p.bh;
-            qb = p.nqb - 1 - id / p.bh;
+            j = id / p.bh;
         }
     }
+    // ---- workgroup j -> one or two query blocks ("segments"), this wave -> (segment, local wave index) ----
+    int n_a, n_b;                                 // units (= query block index + 1) of segments A and B; 0 = none
+    if (j < p.n_alone) {
+        n_a = p.nqb - j;
+        n_b = 0;
+    } else {
+        const int t = j - p.n_alone;
+        n_a = p.n_paired - t;
+        n_b = t + 1;
+        if (n_b == n_a) n_b = 0;                  // middle block of an odd count: alone with half the waves
+    }
+    const int g_a = (n_a + p.chain - 1) / p.chain;             // waves of segment A: [0, g_a)
+    const int g_b = n_b ? (n_b + p.chain - 1) / p.chain : 0;   // waves of segment B: [g_a, g_a + g_b)
+    int n_units, seg_w0, seg_waves, seg;          // units of my query block; first wave / wave count of my segment
+    if (wave < g_a) {
+        seg = 0; n_units = n_a; seg_w0 = 0; seg_waves = g_a;
+    } else if (wave < g_a + g_b) {
+        seg = 1; n_units = n_b; seg_w0 = g_a; seg_waves = g_b;
+    } else {
+        seg = 0; n_units = 0; seg_w0 = wave; seg_waves = 1;       // idle wave: joins the barriers and the row work only
+    }
+    const int wloc = wave - seg_w0;
+    const bool active = n_units > 0;
+    const int qb = n_units - 1;      // causal early exit: units past the diagonal are never touched (CMHSA.cu:133-136)
     const int b = bh / p.num_heads, h = bh - b * p.num_heads;
     const int N = p.seq_len;
     const int q0 = qb * kQBlock;
-    const int n_units = qb + 1;      // causal early exit: units past the diagonal are never touched (CMHSA.cu:133-136)
 
     const float *qg = p.q + b * p.q_bs + (int64_t)h * kHeadDim;
     const float *kg = p.k + b * p.k_bs + (int64_t)h * kHeadDim;
     const float *vg = p.v + b * p.v_bs + (int64_t)h * kHeadDim;
 
     float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: K[0] | K[1] (double-buffered)
-    float *qlds = lds + kWaves * kWaveLdsFloats; // shared: the query block, pre-scaled, K-style swizzle
+    float *qlds_all = lds + kWaves * kWaveLdsFloats;                   // shared: query block of A | of B,
+    float *qlds = qlds_all + seg * kUnitFloats;                        // pre-scaled, K-style swizzle
 
-    // ---- the query block is fetched ONCE per workgroup (each wave 32/kWaves rows), scaled by
-    //      log2(e)/sqrt(64) and parked in LDS; every wave then reads its B-operand fragments from there ----
-    {
-        const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, q0, N);
-        constexpr int kRowsPerWave = kQBlock / kWaves;
-#pragma unroll
-        for (int i = 0; i < kRowsPerWave / 4; ++i) {
-            const int row = wave * kRowsPerWave + 4 * i + (lane >> 4), chunk = lane & 15;
-            f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (row * (int)p.q_rs + chunk * 4) * 4, 0, 0));
-            t *= kScaleLog2;
-            *reinterpret_cast<f32x4 *>(qlds + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = t;
-        }
+    // ---- each segment's query block is fetched ONCE: the 8 (or 16) 4-row groups go round-robin over ALL
+    //      waves of the workgroup, are scaled by log2(e)/sqrt(64) and parked in LDS; every wave then reads
+    //      its B-operand fragments from there ----
+    for (int rg = wave; rg < (n_b ? 16 : 8); rg += kWaves) {
+        const int sg = rg >> 3, row = 4 * (rg & 7) + (lane >> 4), chunk = lane & 15;
+        const int sq0 = ((sg ? n_b : n_a) - 1) * kQBlock;
+        const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, sq0, N);
+        f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (row * (int)p.q_rs + chunk * 4) * 4, 0, 0));
+        t *= kScaleLog2;
+        *reinterpret_cast<f32x4 *>(qlds_all + sg * kUnitFloats + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = t;
     }
 
     // O^T accumulators.  MFMA row i of o0 / o1 is d = 2i / 2i+1, so that one dwordx2 per lane fetches both
@@ -186,7 +230,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     float m_run = -INFINITY;         // running max (log2 domain), same in both lane halves
     float l_run = 0.f;               // running sum over THIS lane half's keys only (merged at the end)
 
-    if (wave < n_units) {
+    if (active) {
         // per-lane byte offsets inside a unit
         const int sub = lane >> 4, chunk = lane & 15;
         const int koff = (sub * (int)p.k_rs + chunk * 4) * 4, kstep = 16 * (int)p.k_rs;   // K: coalesced rows -> LDS
@@ -208,9 +252,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         for (int r = 0; r < 16; ++r) voffs[r] = voff + acc_row(r) * vrs4;
         f32x4 kst[8];                // K staging registers (always one unit ahead of LDS)
         f32x2 vreg[16];              // V of the current unit, MFMA A-operand layout: [k-step r] = {d even, d odd}
-        load_unit(unit_rsrc(kg, p.k_rs, wave * kKeyUnit, N), koff, kstep, kst);
+        load_unit(unit_rsrc(kg, p.k_rs, wloc * kKeyUnit, N), koff, kstep, kst);
+        {
+            const __amdgpu_buffer_rsrc_t vsrc0 = unit_rsrc(vg, p.v_rs, wloc * kKeyUnit, N);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                vreg[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc0, voffs[r], 0, 0));
+        }
         store_unit<true>(wlds, lane, kst);
-        load_unit(unit_rsrc(kg, p.k_rs, (wave + kWaves) * kKeyUnit, N, wave + kWaves < n_units), koff, kstep, kst);
+        load_unit(unit_rsrc(kg, p.k_rs, (wloc + seg_waves) * kKeyUnit, N, wloc + seg_waves < n_units), koff, kstep, kst);
         __syncthreads();             // Q block complete in LDS (every wave of the workgroup reaches this)
         float qf[32];                // Q^T fragment: B operand of S^T = K Q^T; k-step 4c+j uses d = 8c + 4*half + j
 #pragma unroll
@@ -223,24 +273,18 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         int cur = 0;
         STAMP(1);
 
-        for (int u = wave; u < n_units; u += kWaves) {
-            const bool has_next = u + kWaves < n_units;
+        for (int u = wloc; u < n_units; u += seg_waves) {
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i);
 #endif
             // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] : 32 chained MFMAs.  K fragments are read
             //      two steps (512 MFMA cycles) ahead. ----
-            //      V(u) goes straight into its MFMA operand registers, two loads per step: memory instructions
-            //      between MFMAs are free, and the loads have the rest of the chain + the softmax to land.
-            const __amdgpu_buffer_rsrc_t vsrc = unit_rsrc(vg, p.v_rs, u * kKeyUnit, N);
             f32x16 s = {0};
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const f32x4 kk = kcur;
                 kcur = knext;
                 if (c + 2 < 8) knext = kfrag(cur, c + 2);
-                vreg[2 * c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc, voffs[2 * c], 0, 0));
-                vreg[2 * c + 1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc, voffs[2 * c + 1], 0, 0));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -299,7 +343,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             //        steps 8-15 : K(u+2) global -> staging registers;  steps 13,14: first K(u+1) fragments ----
             //      Everything is unconditional (past the last unit the descriptors have zero records and the
             //      LDS traffic goes to the idle buffer), so the chain stays one basic block.
-            const __amdgpu_buffer_rsrc_t ksrc2 = unit_rsrc(kg, p.k_rs, (u + 2 * kWaves) * kKeyUnit, N, u + 2 * kWaves < n_units);
+            const __amdgpu_buffer_rsrc_t ksrc2 = unit_rsrc(kg, p.k_rs, (u + 2 * seg_waves) * kKeyUnit, N, u + 2 * seg_waves < n_units);
+            const __amdgpu_buffer_rsrc_t vsrc1 = unit_rsrc(vg, p.v_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < n_units);
             float *knew = wlds + (cur ^ 1) * kUnitFloats;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -319,6 +364,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r][0], s[r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r][1], s[r], o1, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                // V(u+1), k-step r: its operand registers are free as soon as the two MFMAs above have issued;
+                // the load has the whole next QK chain + softmax to land
+                vreg[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc1, voffs[r], 0, 0));
             }
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 3);
@@ -334,56 +382,67 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     STAMP(2);
 #endif
 
-    // ---- merge the split-KV partials (idle waves carry m=-inf, l=0, O=0).
-    //      1. every wave publishes its (m, l);  2. every lane derives ITS wave's final weight
-    //      exp2(m_w - m_tot) / l_tot for its query, scales its O registers and writes them to its own
-    //      [64 d][33] image;  3. thread (query, d) adds the kWaves images and stores whole 256-B rows. ----
-    constexpr int kMlOff = kHeadDim * kCombStride;       // m[32] | l[32] sit behind the O image of each wave's own region
+    // ---- merge the split-KV partials of each segment: ONE barrier, no transposition.
+    //      Every active wave publishes its un-normalised O accumulators in their native MFMA layout, as 8
+    //      float4 "pairs" per lane -- pair pi = {o0[2pi], o1[2pi], o0[2pi+1], o1[2pi+1]} = 4 consecutive d
+    //      of the lane's query -- plus its (m, l).  After the barrier the 8 (or 16) (segment, pair) items go
+    //      round-robin over ALL waves: an item reads the pair of every wave of its segment, weights it with
+    //      exp2(m_w - m_tot), divides by the merged l and stores one float4 per lane straight to O. ----
+    constexpr int kMlOff = 8 * 64 * 4;                   // m[32] | l[32] sit behind the 8 KiB of pairs
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < 32) {
-        wlds[kMlOff + lane] = m_run;
-        wlds[kMlOff + 32 + lane] = l_run;
+    if (active) {
+        f32x4 *pub = reinterpret_cast<f32x4 *>(wlds);
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) {
+            const f32x4 t = {o0[2 * pi], o1[2 * pi], o0[2 * pi + 1], o1[2 * pi + 1]};
+            pub[pi * 64 + lane] = t;
+        }
+        if (lane < 32) {
+            wlds[kMlOff + lane] = m_run;
+            wlds[kMlOff + 32 + lane] = l_run;
+        }
     }
     __syncthreads();
+    STAMP(120);
     {
-        float m_tot = -INFINITY, mw[kWaves], lw[kWaves];
+        float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
+        for (int item = wave; item < (n_b ? 16 : 8); item += kWaves) {       // wave-uniform trip count
+            const int sg = item >> 3, pi = item & 7;
+            const int w_lo = sg ? g_a : 0, w_hi = sg ? g_a + g_b : g_a;
+            // wave-uniform bit masks instead of selects keep the LDS reads unconditional and back to back
+            // (hipcc turns a uniform select of a load into a branch with a full lgkmcnt(0) wait per read)
+            float mw[kWaves], lw[kWaves];
+            f32x4 ow[kWaves];
+            float m_tot = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            mw[w] = lds[w * kWaveLdsFloats + kMlOff + l31];
-            lw[w] = lds[w * kWaveLdsFloats + kMlOff + 32 + l31];
-            m_tot = fmaxf(m_tot, mw[w]);
+            for (int w = 0; w < kWaves; ++w) {
+                const unsigned mine = (w >= w_lo && w < w_hi) ? 0xffffffffu : 0u;
+                const float *base = lds + w * kWaveLdsFloats;
+                const float mv = base[kMlOff + l31], lv = base[kMlOff + 32 + l31];
+                const u32x4 ov = *reinterpret_cast<const u32x4 *>(base + (pi * 64 + lane) * 4);
+                mw[w] = __uint_as_float((__float_as_uint(mv) & mine) | (~mine & 0xff800000u));   // -inf when not mine
+                lw[w] = __uint_as_float(__float_as_uint(lv) & mine);
+                ow[w] = __builtin_bit_cast(f32x4, ov & mine);
+                m_tot = fmaxf(m_tot, mw[w]);
+            }
+            float l_tot = 0.f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                const float f = __builtin_amdgcn_exp2f(mw[w] - m_tot);
+                l_tot += lw[w] * f;
+                acc += ow[w] * f;
+            }
+            acc *= 1.0f / l_tot;
+            const int row = ((sg ? n_b : n_a) - 1) * kQBlock + l31;
+            const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);       // = 2 * (acc_row(2 pi) + 4 half)
+            if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
         }
-        float l_tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) l_tot += lw[w] * __builtin_amdgcn_exp2f(mw[w] - m_tot);
-        const float f = __builtin_amdgcn_exp2f(m_run - m_tot) / l_tot;
-        float *ob = wlds;                                // this wave's own region: [64 d][33]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = 2 * (acc_row(r) + 4 * half);
-            ob[d * kCombStride + l31] = o0[r] * f;
-            ob[(d + 1) * kCombStride + l31] = o1[r] * f;
-        }
-    }
-    __syncthreads();
-    float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
-    constexpr int kRows = kQBlock / kWaves;
-    float acc[kRows];
-#pragma unroll
-    for (int i = 0; i < kRows; ++i) {
-        const int q = wave + kWaves * i;
-        acc[i] = 0.f;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) acc[i] += lds[w * kWaveLdsFloats + lane * kCombStride + q];
-    }
-#pragma unroll
-    for (int i = 0; i < kRows; ++i) {
-        const int q = wave + kWaves * i;
-        if (q0 + q < N) og[(int64_t)(q0 + q) * p.o_rs + lane] = acc[i];      // wave-uniform predicate
     }
 #ifdef CMHSA_STAMPS
     STAMP(3);
+    if (g_block_times && threadIdx.x == 0) g_block_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -406,12 +465,11 @@ hipError_t launch(const Params &p, int64_t blocks, void *stream) {
     return hipSuccess;
 }
 
-// Waves per workgroup.  Measured on MI355X (tools/cmhsa_bench, profiles/): with more than ~2 workgroups per
-// CU the 4-wave form wins (two co-resident workgroups hide each other's prologue and merge: +7..12 %);
-// when the grid is between one and two rounds of 8-wave workgroups (BASELINE config 2: 384 blocks on 256
-// CUs) the 8-wave form wins because the longest query block's chain is half as long (-12 %).
+// Waves per workgroup.  8-wave workgroups (one per CU) halve the longest query block's chain: they win while
+// the whole grid fits in about one round of CUs; beyond that two co-resident 4-wave workgroups per CU hide
+// each other's prologue and merge (measured on MI355X with tools/cmhsa_bench, see profiles/).
 // CMHSA_WAVES=4|8 in the environment overrides (read once; for experiments).
-int choose_waves(int64_t blocks, int nqb) {
+int choose_waves(int64_t bh, int nqb) {
     static const int forced = [] {
         const char *e = getenv("CMHSA_WAVES");
         return e ? atoi(e) : 0;
@@ -422,8 +480,8 @@ int choose_waves(int64_t blocks, int nqb) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    (void)nqb;
-    return (blocks > cus && blocks <= 5 * (int64_t)cus / 2) ? 8 : 4;
+    const int64_t blocks8 = bh * pack_plan(nqb, 8).wgs_per_bh;
+    return blocks8 <= 5 * (int64_t)cus / 4 ? 8 : 4;
 }
 
 }  // namespace
@@ -451,6 +509,9 @@ int cmhsa_debug_set_stamps(unsigned long long *buf, int block) {
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_block), &block, sizeof(block));
     return (int)e;
 }
+int cmhsa_debug_set_block_times(unsigned long long *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_block_times), &buf, sizeof(buf));
+}
 #endif
 
 double cmhsa_algorithmic_flops(int batch, int seq_len, int num_heads, int head_dim) {
@@ -473,8 +534,15 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
 
     const int64_t nqb = ((int64_t)seq_len + kQBlock - 1) / kQBlock;
     const int64_t bh = (int64_t)batch * num_heads;
-    const int64_t blocks = bh * nqb;
-    if (blocks > 0x7fffffffLL || bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    if (nqb > 0x3fffffffLL || bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    // 32-bit byte offsets inside a 32-row unit (buffer loads): 32 rows * row_stride * 4 B must fit
+    const int64_t max_rs = q_row_stride > k_row_stride ? q_row_stride : k_row_stride;
+    if ((max_rs > v_row_stride ? max_rs : v_row_stride) > (1LL << 24)) return CMHSA_ERR_TOO_LARGE;
+
+    const int waves = choose_waves(bh, (int)nqb);
+    const PackPlan pl = pack_plan((int)nqb, waves);
+    const int64_t blocks = bh * pl.wgs_per_bh;
+    if (blocks > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
 
     Params p;
     p.q = q; p.k = k; p.v = v; p.o = o;
@@ -485,8 +553,8 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     p.bh = (int)bh;
     p.nqb = (int)nqb;
     p.xcd_map = (bh % 8 == 0) ? 1 : 0;
+    p.chain = pl.chain; p.n_paired = pl.n_paired; p.n_alone = pl.n_alone; p.wgs_per_bh = pl.wgs_per_bh;
 
-    const int waves = choose_waves(blocks, (int)nqb);
     hipError_t e = waves == 8 ? launch<8>(p, blocks, stream) : launch<4>(p, blocks, stream);
     if (e != hipSuccess) return (int)e;
     e = hipGetLastError();                 // launch-configuration errors only; no synchronisation (CMHSA.cu:450)

@@ -218,7 +218,7 @@ def test_full_size_properties_config5_shape(gpu_device):
     assert torch.allclose(o1[:, 0], V1[:, 0], atol=1e-6)                          # first row
     const = torch.arange(d, device=gpu_device, dtype=torch.float32).expand(B, T, d).contiguous()
     oc = cmhsa.attention_fwd(Q, K, const, H)
-    assert (oc - const).abs().max().item() <= 1e-3 * d / 1024 + 2e-4              # softmax rows sum to 1
+    assert (oc - const).abs().max().item() <= 5e-6 * d                            # rows of softmax sum to 1 (relative 5e-6 of max |V|)
     for b, h in ((0, 0), (3, 15), (2, 7)):
         sl = slice(64 * h, 64 * h + 64)
         want = oracle.naive_attention_f64(Q[b, :, sl].cpu().numpy(), K[b, :, sl].cpu().numpy(),

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
+#include <algorithm>
 
 #include "cmhsa.h"
 
@@ -16,6 +17,7 @@
 
 #ifdef CMHSA_STAMPS
 extern "C" int cmhsa_debug_set_stamps(unsigned long long *buf, int block);
+extern "C" int cmhsa_debug_set_block_times(unsigned long long *buf);
 #endif
 
 int main(int argc, char **argv) {
@@ -53,6 +55,26 @@ int main(int argc, char **argv) {
     printf("{\"B\": %d, \"H\": %d, \"T\": %d, \"steps\": %d, \"us_per_launch\": %.3f, \"tflops\": %.3f, \"frac_of_157.3\": %.4f, \"o00\": %.6f}\n",
            B, H, T, steps, us, flops / us / 1e6, flops / us / 1e6 / 157.3, ho[0]);
 #ifdef CMHSA_STAMPS
+    {   // per-workgroup entry/exit times (s_memrealtime, 10 ns ticks) of one launch: dispatch ramp and tail
+        const int maxb = 1 << 16;
+        unsigned long long *bt = nullptr;
+        CHECK(hipMalloc(&bt, 2 * maxb * sizeof(unsigned long long)));
+        CHECK(hipMemset(bt, 0, 2 * maxb * sizeof(unsigned long long)));
+        if (cmhsa_debug_set_block_times(bt)) return 1;
+        for (int i = 0; i < 3; ++i) run();
+        CHECK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hb(2 * maxb);
+        CHECK(hipMemcpy(hb.data(), bt, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        cmhsa_debug_set_block_times(nullptr);
+        unsigned long long t0 = ~0ull; int nb = 0;
+        for (int i = 0; i < maxb; ++i) if (hb[2 * i]) { nb = i + 1; if (hb[2 * i] < t0) t0 = hb[2 * i]; }
+        printf("blocks %d; per block: start_us end_us (relative to first start)\n", nb);
+        for (int i = 0; i < nb; i += (nb > 64 ? nb / 48 : 1))
+            printf("  blk %4d: %7.2f %7.2f\n", i, (hb[2 * i] - t0) * 0.01, (hb[2 * i + 1] - t0) * 0.01);
+        double last_start = 0, last_end = 0;
+        for (int i = 0; i < nb; ++i) { last_start = std::max(last_start, (hb[2 * i] - t0) * 0.01); last_end = std::max(last_end, (hb[2 * i + 1] - t0) * 0.01); }
+        printf("  last start %.2f us, last end %.2f us\n", last_start, last_end);
+    }
     {   // one extra launch with stamps of workgroup `argv[6]` (default 0 = a heaviest query block)
         unsigned long long *sb = nullptr;
         CHECK(hipMalloc(&sb, 8 * 128 * sizeof(unsigned long long)));
@@ -67,7 +89,8 @@ int main(int argc, char **argv) {
             const unsigned long long *p = &hs[w * 128];
             printf("wave %d: entry %lld  q_loaded %lld  loop_end %lld  done %lld | units (top, qk_start, qk_issued, pv_start):\n", w,
                    (long long)(p[0] - t0), (long long)(p[1] - t0), (long long)(p[2] - t0), (long long)(p[3] - t0));
-            for (int i = 4; i + 3 < 128 && p[i]; i += 4)
+            printf("    merge: ml_published %lld  images_written %lld  after_barrier %lld\n", (long long)(p[120] - t0), (long long)(p[121] - t0), (long long)(p[122] - t0));
+            for (int i = 4; i + 3 < 120 && p[i]; i += 4)
                 printf("    %lld %lld %lld %lld\n", (long long)(p[i] - t0), (long long)(p[i + 1] - t0), (long long)(p[i + 2] - t0), (long long)(p[i + 3] - t0));
         }
     }
