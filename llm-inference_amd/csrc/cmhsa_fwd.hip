@@ -252,16 +252,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         for (int r = 0; r < 16; ++r) voffs[r] = voff + acc_row(r) * vrs4;
         f32x4 kst[8];                // K staging registers (always one unit ahead of LDS)
         f32x2 vreg[16];              // V of the current unit, MFMA A-operand layout: [k-step r] = {d even, d odd}
+        // Only what the first QK chain needs (K(u0), and the Q block above) is requested before the barrier:
+        // a CU's L1 fills at 64 B/clk, and every byte queued ahead of another wave's K(u0) delays the
+        // whole workgroup's start.  V(u0) and K(u1) follow behind the barrier.
         load_unit(unit_rsrc(kg, p.k_rs, wloc * kKeyUnit, N), koff, kstep, kst);
+        store_unit<true>(wlds, lane, kst);
+        __syncthreads();             // Q block complete in LDS (every wave of the workgroup reaches this)
         {
             const __amdgpu_buffer_rsrc_t vsrc0 = unit_rsrc(vg, p.v_rs, wloc * kKeyUnit, N);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 vreg[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc0, voffs[r], 0, 0));
         }
-        store_unit<true>(wlds, lane, kst);
         load_unit(unit_rsrc(kg, p.k_rs, (wloc + seg_waves) * kKeyUnit, N, wloc + seg_waves < n_units), koff, kstep, kst);
-        __syncthreads();             // Q block complete in LDS (every wave of the workgroup reaches this)
         float qf[32];                // Q^T fragment: B operand of S^T = K Q^T; k-step 4c+j uses d = 8c + 4*half + j
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -466,8 +469,9 @@ hipError_t launch(const Params &p, int64_t blocks, void *stream) {
 }
 
 // Waves per workgroup.  8-wave workgroups (one per CU) halve the longest query block's chain: they win while
-// the whole grid fits in about one round of CUs; beyond that two co-resident 4-wave workgroups per CU hide
-// each other's prologue and merge (measured on MI355X with tools/cmhsa_bench, see profiles/).
+// the packed grid fits in one round of CUs (BASELINE config 2: 216 workgroups, 23.9 vs 24.7 us); beyond that
+// two co-resident 4-wave workgroups per CU hide each other's prologue and merge (B=16 T=1024: 288 vs 315 us).
+// Measured on MI355X with tools/cmhsa_bench, see profiles/.
 // CMHSA_WAVES=4|8 in the environment overrides (read once; for experiments).
 int choose_waves(int64_t bh, int nqb) {
     static const int forced = [] {
@@ -480,8 +484,7 @@ int choose_waves(int64_t bh, int nqb) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    const int64_t blocks8 = bh * pack_plan(nqb, 8).wgs_per_bh;
-    return blocks8 <= 5 * (int64_t)cus / 4 ? 8 : 4;
+    return bh * pack_plan(nqb, 8).wgs_per_bh <= cus ? 8 : 4;
 }
 
 }  // namespace
