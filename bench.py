@@ -150,6 +150,41 @@ def main() -> None:
     value = world * flops / (wall / args.steps) / 1e12
     launch_us = dev_ms * 1e3 / args.steps
     achieved = flops / (dev_ms * 1e-3 / args.steps) / 1e12
+
+    # HBM traffic per launch from the committed rocprofv3 counter passes of this same workload
+    # (tools/prof_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, KiB -> bytes)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_summary.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
+
+    # secondary evidence (N=1 only, outside the timed region): the throughput-regime shape
+    others = {}
+    if world == 1 and args.workload == "config2":
+        for name in ("config5_shard",):
+            o = WORKLOADS[name]
+            x = torch.rand((o["B"], o["T"], 3 * 64 * o["H"]), device=dev)
+            dd = 64 * o["H"]
+            oq, ok, ov = x[..., :dd], x[..., dd:2 * dd], x[..., 2 * dd:]
+            oo = torch.empty((o["B"], o["T"], dd), device=dev)
+            a = (oq.data_ptr(), ok.data_ptr(), ov.data_ptr(), oo.data_ptr(), oq.stride(1), ok.stride(1), ov.stride(1), oo.stride(1),
+                 oq.stride(0), ok.stride(0), ov.stride(0), oo.stride(0), o["B"], o["T"], o["H"], 64, ctypes.c_void_p(stream.cuda_stream))
+            for _ in range(3):
+                fwd(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(10):
+                fwd(*a)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) * 1e3 / 10
+            tf = cmhsa.algorithmic_flops(o["B"], o["T"], o["H"], 64) / us / 1e6
+            others[name] = {"workload": o["desc"], "us_per_launch": round(us, 2), "tflops": round(tf, 2),
+                            "frac_of_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+            del x, oo
     result = {
         "metric": "attention fp32 TFLOP/s (causal MHSA forward, F = 2*B*H*d*T*(T+1))",
         "value": round(value, 3),
@@ -166,7 +201,7 @@ def main() -> None:
         "config": {"workload": wl["desc"], "batch_per_gpu": B, "num_heads": H, "seq_len": T, "head_dim": 64,
                    "parallelism": f"dp{world} (independent prompts per GPU, no data-path collective)"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "kernel": "cmhsa_fwd_kernel", "avg_launch_us": round(launch_us, 3),
                      "flops_per_launch": flops, "bytes_per_launch_algorithmic": 4 * B * T * d * 4,
                      "timing": "HIP events on the launch stream around the timed steps (includes inter-launch gaps)"},
@@ -174,6 +209,8 @@ def main() -> None:
         "max_abs_err_vs_f64_oracle": max_err,
         "device": torch.cuda.get_device_name(dev),
     }
+    if others:
+        result["other_workloads"] = others
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(wl)
     if world > 1:
