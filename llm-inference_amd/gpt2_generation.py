@@ -1,0 +1,260 @@
+"""GPT-2 greedy generation harness around the attention op (BASELINE configs 1, 3, 4).
+
+Counterpart -- not a copy -- of the reference's driver stack:
+  model          reference gpt2.py:28-56 (GPT2), transformer_block.py:8-39, feed_forward.py:6-19, gelu.py:4-12
+  configs        reference gpt2.py:58-73   (small / medium / large / xl)
+  weight load    reference gpt2.py:16-25, :47-56 + safetensors_utils.py:6-24 (HF names, Conv1D weights transposed,
+                 LM head tied to wte) -- from a LOCAL model.safetensors only (no network here)
+  greedy loop    reference sampler.py:10-21 (full re-forward per token, no KV cache; stop at EOS or when the TOTAL
+                 length reaches max_tokens; logits[0,-1,:] -> argmax -> append)
+  timing         reference gpt2.py:93-134  (warm-up of prompt+3 tokens, then one timed run)
+
+Differences: batch > 1 (independent prompts, config 4) with per-row EOS handling; prompts are token ids (tiktoken is
+not installed offline; the reference prompt "Hello, I'm a language model," is supplied as ids); without --weights the
+model has seeded random weights, which keeps the token-identity check (naive vs HIP backend) valid and harsh.
+
+    python llm-inference_amd/gpt2_generation.py --backend CUSTOM_CUDA --model gpt2 --device cuda --max-tokens 512
+    python -m torch.distributed.run --nproc-per-node N ... gpt2_generation.py --batch 64 --model gpt2-xl   (DP over prompts)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+from causal_self_attention import CausalSelfAttention, ScaledDotProductAttentionBackend  # noqa: E402
+
+# "Hello, I'm a language model," under the GPT-2 BPE (reference gpt2.py:143).  From memory, NOT re-verified here:
+# tiktoken is not installed in this image and would need the network for its BPE files.
+REFERENCE_PROMPT_IDS = (15496, 11, 314, 1101, 257, 3303, 2746, 11)
+EOS_TOKEN = 50256            # <|endoftext|>, reference tokenizer.py:30-31
+
+GPT2_CONFIGS = {             # reference gpt2.py:59-71
+    "gpt2":        dict(emb_dim=768,  n_heads=12, n_layers=12),
+    "gpt2-medium": dict(emb_dim=1024, n_heads=16, n_layers=24),
+    "gpt2-large":  dict(emb_dim=1280, n_heads=20, n_layers=36),
+    "gpt2-xl":     dict(emb_dim=1600, n_heads=25, n_layers=48),
+}
+COMMON = dict(vocab_size=50257, context_length=1024, drop_rate=0.1, qkv_bias=True)
+
+
+def tanh_gelu(x: torch.Tensor) -> torch.Tensor:
+    """The reference's GELU, same expression tree (gelu.py:9-12)."""
+    return 0.5 * x * (1 + torch.tanh(torch.sqrt(torch.tensor(2.0 / torch.pi)) * (x + 0.44715 * torch.pow(x, 3))))
+
+
+class Block(nn.Module):
+    """Pre-LN block: x + attn(LN(x)); x + mlp(LN(x)) (transformer_block.py:26-39); dropouts are identity in eval()."""
+
+    def __init__(self, cfg: dict, backend: ScaledDotProductAttentionBackend):
+        super().__init__()
+        d = cfg["emb_dim"]
+        self.first_layer_norm = nn.LayerNorm(d)
+        self.attention = CausalSelfAttention(d_in=d, d_out=d, max_context_length=cfg["context_length"],
+                                             p_dropout=cfg["drop_rate"], num_heads=cfg["n_heads"],
+                                             qkv_bias=cfg["qkv_bias"], scaled_dot_product_attention_backend=backend)
+        self.second_layer_norm = nn.LayerNorm(d)
+        self.mlp_in = nn.Linear(d, 4 * d)
+        self.mlp_out = nn.Linear(4 * d, d)
+
+    def forward(self, x):
+        x = x + self.attention(self.first_layer_norm(x))
+        return x + self.mlp_out(tanh_gelu(self.mlp_in(self.second_layer_norm(x))))
+
+
+class GPT2Model(nn.Module):
+    def __init__(self, cfg: dict, backend: ScaledDotProductAttentionBackend, last_position_only: bool = False):
+        super().__init__()
+        self.cfg = cfg
+        self.last_position_only = last_position_only      # opt-in; default = reference behaviour
+        self.token_embeddings = nn.Embedding(cfg["vocab_size"], cfg["emb_dim"])
+        self.positional_embeddings = nn.Embedding(cfg["context_length"], cfg["emb_dim"])
+        self.blocks = nn.ModuleList(Block(cfg, backend) for _ in range(cfg["n_layers"]))
+        self.layer_norm = nn.LayerNorm(cfg["emb_dim"])
+        self.output_layer = nn.Linear(cfg["emb_dim"], cfg["vocab_size"], bias=False)
+
+    def forward(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens (B, T) -> logits (B, T, vocab) (reference gpt2.py:41-45), or (B, 1, vocab) with last_position_only."""
+        n = tokens.shape[1]
+        x = self.token_embeddings(tokens) + self.positional_embeddings(torch.arange(n, device=tokens.device))
+        for blk in self.blocks:
+            x = blk(x)
+        x = self.layer_norm(x)
+        if self.last_position_only:
+            x = x[:, -1:, :]
+        return self.output_layer(x)
+
+    @torch.no_grad()
+    def load_hf_safetensors(self, path: str) -> None:
+        """HF GPT-2 checkpoint names; Conv1D weights are stored (in, out) and transposed here; LM head = wte."""
+        from safetensors import safe_open
+
+        def put(param, t, transpose=False):
+            t = t.T if transpose else t
+            if param.shape != t.shape:
+                raise ValueError(f"shape mismatch: parameter {tuple(param.shape)} vs checkpoint {tuple(t.shape)}")
+            param.copy_(t)
+
+        with safe_open(path, framework="pt") as f:
+            g = lambda k: f.get_tensor(k) if k in f.keys() else f.get_tensor("transformer." + k)
+            put(self.token_embeddings.weight, g("wte.weight"))
+            put(self.positional_embeddings.weight, g("wpe.weight"))
+            put(self.output_layer.weight, g("wte.weight"))
+            put(self.layer_norm.weight, g("ln_f.weight")); put(self.layer_norm.bias, g("ln_f.bias"))
+            for i, b in enumerate(self.blocks):
+                p = f"h.{i}."
+                put(b.first_layer_norm.weight, g(p + "ln_1.weight")); put(b.first_layer_norm.bias, g(p + "ln_1.bias"))
+                put(b.second_layer_norm.weight, g(p + "ln_2.weight")); put(b.second_layer_norm.bias, g(p + "ln_2.bias"))
+                put(b.attention.qkv_layer.weight, g(p + "attn.c_attn.weight"), True); put(b.attention.qkv_layer.bias, g(p + "attn.c_attn.bias"))
+                put(b.attention.out_proj_layer.weight, g(p + "attn.c_proj.weight"), True); put(b.attention.out_proj_layer.bias, g(p + "attn.c_proj.bias"))
+                put(b.mlp_in.weight, g(p + "mlp.c_fc.weight"), True); put(b.mlp_in.bias, g(p + "mlp.c_fc.bias"))
+                put(b.mlp_out.weight, g(p + "mlp.c_proj.weight"), True); put(b.mlp_out.bias, g(p + "mlp.c_proj.bias"))
+
+
+def build_model(name: str, backend: ScaledDotProductAttentionBackend, device, weights: str | None = None, seed: int = 0,
+                last_position_only: bool = False, overrides: dict | None = None) -> GPT2Model:
+    cfg = {**COMMON, **GPT2_CONFIGS[name], **(overrides or {})}
+    torch.manual_seed(seed)                       # seeded random weights unless a local checkpoint is given
+    model = GPT2Model(cfg, backend, last_position_only)
+    if weights:
+        model.load_hf_safetensors(weights)
+    return model.eval().to(device)
+
+
+@torch.no_grad()
+def greedy_generate(model: nn.Module, prompt_ids, max_tokens: int, eos_token: int = EOS_TOKEN, device=None) -> list[list[int]]:
+    """Greedy decoding with the reference's loop semantics (sampler.py:14-19), for one prompt or a batch of
+    equal-length prompts.  A row that has produced EOS keeps being padded with EOS and ignored; the loop ends when
+    every row has hit EOS or the total length reaches max_tokens.  Returns the token lists (EOS-padded rows trimmed
+    after their first EOS)."""
+    device = device or next(model.parameters()).device
+    text = torch.as_tensor(prompt_ids, dtype=torch.long, device=device)
+    if text.dim() == 1:
+        text = text.unsqueeze(0)
+    plen = text.shape[1]
+    done = torch.zeros(text.shape[0], dtype=torch.bool, device=device)
+    while text.shape[1] < max_tokens and not bool(done.all()):
+        logits = model(text)                                       # (B, T or 1, vocab): full re-forward, no KV cache
+        nxt = torch.argmax(logits[:, -1, :], dim=-1)               # first max wins, as torch.argmax in the reference
+        nxt = torch.where(done, torch.full_like(nxt, eos_token), nxt)
+        text = torch.cat((text, nxt.unsqueeze(1)), dim=1)
+        done |= nxt == eos_token
+    out = []
+    for row in text.tolist():
+        cut = len(row)
+        for i in range(plen, len(row)):
+            if row[i] == eos_token:
+                cut = i + 1
+                break
+        out.append(row[:cut])
+    return out
+
+
+@dataclass
+class GenerationTiming:
+    first_run_seconds: float
+    second_run_seconds: float
+    max_gpu_memory_allocated_bytes: int
+    tokens: list
+
+
+def time_greedy_generation(model, prompt_ids, max_tokens: int, device) -> GenerationTiming:
+    """Mirror of reference gpt2.py:104-134: warm-up run of prompt+3 tokens, then the timed run."""
+    plen = len(prompt_ids[0]) if isinstance(prompt_ids[0], (list, tuple)) else len(prompt_ids)
+    sync = (lambda: torch.cuda.synchronize(device)) if torch.device(device).type == "cuda" else (lambda: None)
+    t0 = time.perf_counter_ns()
+    greedy_generate(model, prompt_ids, plen + 3, device=device)
+    sync()
+    first = (time.perf_counter_ns() - t0) / 1e9
+    torch.manual_seed(0)
+    if torch.device(device).type == "cuda":
+        torch.cuda.reset_peak_memory_stats(device)
+    t0 = time.perf_counter_ns()
+    toks = greedy_generate(model, prompt_ids, max_tokens, device=device)
+    sync()
+    second = (time.perf_counter_ns() - t0) / 1e9
+    peak = torch.cuda.max_memory_allocated(device) if torch.device(device).type == "cuda" else 0
+    return GenerationTiming(first, second, peak, toks)
+
+
+def shard_prompts(n_prompts: int, rank: int, world: int) -> range:
+    """Data-parallel split of independent prompts: contiguous, sizes differ by at most one (config 4)."""
+    base, extra = divmod(n_prompts, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="CUSTOM_CUDA", choices=[b.name for b in ScaledDotProductAttentionBackend])
+    ap.add_argument("--model", default="gpt2", choices=list(GPT2_CONFIGS))
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--max-tokens", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1, help="number of copies of the reference prompt (all ranks together)")
+    ap.add_argument("--weights", default=None, help="local HF model.safetensors; default: seeded random weights")
+    ap.add_argument("--last-position-lm-head", action="store_true")
+    ap.add_argument("--threads", type=int, default=0, help="CPU threads for --device cpu (0 = all cores)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = ScaledDotProductAttentionBackend[args.backend]
+    if args.device == "cuda":
+        if not torch.cuda.is_available():
+            raise SystemExit("no GPU visible (the CUSTOM_CUDA backend has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+        torch.set_num_threads(args.threads or (os.cpu_count() or 1))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl" if device.type == "cuda" else "gloo",
+                                **({"device_id": device} if device.type == "cuda" else {}))
+
+    model = build_model(args.model, backend, device, weights=args.weights, last_position_only=args.last_position_lm_head)
+    mine = shard_prompts(args.batch, rank, world)
+    prompts = [list(REFERENCE_PROMPT_IDS) for _ in mine]
+    if world > 1:
+        dist.barrier()
+    timing = time_greedy_generation(model, prompts, args.max_tokens, device) if prompts else GenerationTiming(0, 0, 0, [])
+    seconds = timing.second_run_seconds
+    generated = sum(len(t) - len(REFERENCE_PROMPT_IDS) for t in timing.tokens)
+    if world > 1:
+        agg = torch.tensor([seconds, float(generated)], dtype=torch.float64, device=device)
+        mx = agg.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        seconds, generated = float(mx[0]), int(agg[1])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, timing.tokens)          # token ids only: <= batch * max_tokens * 8 B
+        tokens = [t for part in gathered for t in part]
+        dist.destroy_process_group()
+    else:
+        tokens = timing.tokens
+    if rank == 0:
+        print(json.dumps({
+            "model": args.model, "backend": args.backend, "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
+            "cpu_threads": torch.get_num_threads() if device.type == "cpu" else None,
+            "weights": args.weights or "random (torch.manual_seed(0))", "prompts": args.batch, "max_tokens": args.max_tokens,
+            "warmup_seconds": round(timing.first_run_seconds, 4), "seconds": round(seconds, 4),
+            "tokens_generated": generated, "tokens_per_second": round(generated / seconds, 2) if seconds else None,
+            "max_gpu_memory_allocated_kib": timing.max_gpu_memory_allocated_bytes // 1024,
+            "first_tokens": tokens[0][:24] if tokens else [],
+        }))
+
+
+if __name__ == "__main__":
+    main()
