@@ -38,6 +38,10 @@ WORKLOADS = {
     "config2": dict(B=1, H=12, T=1024, desc="standalone causal attention fp32 B=1 H=12 T=1024 d_head=64 (QKV-sliced inputs)"),
     # one GPU's share of BASELINE.json configs[4] (B=32, H=16, T=4096 head-sharded 8 ways -> 2 heads per GPU)
     "config5_shard": dict(B=32, H=2, T=4096, desc="one GPU's head shard of B=32 H=16 T=4096 d_head=64 (2 heads)"),
+    # BASELINE.json configs[4] itself: heads split over the N ranks, one RCCL all-gather of the context slabs
+    # (strong scaling: total work fixed; N=1 runs all 16 heads on one GPU and gathers nothing)
+    "config5": dict(B=32, H=16, T=4096, head_sharded=True,
+                    desc="synthetic causal attention fp32 B=32 H=16 T=4096 d_head=64, head-sharded over N GPUs + one all-gather"),
 }
 
 
@@ -99,6 +103,11 @@ def main() -> None:
     lib = cmhsa.load_library()
     wl = WORKLOADS[args.workload]
     B, H, T = wl["B"], wl["H"], wl["T"]
+    sharded = bool(wl.get("head_sharded"))
+    if sharded:
+        if H % world != 0:
+            raise SystemExit(f"config5 needs num_heads ({H}) divisible by the number of GPUs ({world})")
+        H = H // world                                   # this rank's heads: a column slab of Q, K, V
     d = 64 * H
     torch.manual_seed(1234 + rank)
     qkv = torch.rand((B, T, 3 * d), device=dev)                      # reference test distribution (test_torch_extension.py:16-18)
@@ -111,10 +120,14 @@ def main() -> None:
                  B, T, H, 64, ctypes.c_void_p(stream.cuda_stream))
     fwd = lib.cmhsa_fp32_fwd
 
+    gathered = torch.empty((world * B, T, d), device=dev) if sharded and world > 1 else None
+
     def step() -> None:
         rc = fwd(*call_args)
         if rc != 0:
             raise RuntimeError(cmhsa.status_string(rc))
+        if gathered is not None:                         # the one collective of the head-sharded form
+            dist.all_gather_into_tensor(gathered, out)
 
     def fence() -> None:
         if world > 1:
@@ -145,7 +158,7 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tmax[0]), float(tmax[1])
 
-    flops = cmhsa.algorithmic_flops(B, T, H, 64)
+    flops = cmhsa.algorithmic_flops(B, T, H, 64)              # per rank
     ms_per_step = wall * 1e3 / args.steps
     value = world * flops / (wall / args.steps) / 1e12
     launch_us = dev_ms * 1e3 / args.steps
@@ -194,12 +207,13 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 6),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if sharded else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (torch.rand U[0,1), seeded), inputs resident in HBM",
         "config": {"workload": wl["desc"], "batch_per_gpu": B, "num_heads": H, "seq_len": T, "head_dim": 64,
-                   "parallelism": f"dp{world} (independent prompts per GPU, no data-path collective)"},
+                   "parallelism": (f"heads/{world} per GPU + one all-gather of (B,T,{d}) fp32 slabs" if sharded else
+                                   f"dp{world} (independent prompts per GPU, no data-path collective)")},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "kernel": "cmhsa_fwd_kernel", "avg_launch_us": round(launch_us, 3),

@@ -1,0 +1,76 @@
+"""Multi-GPU forms of the attention path; one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+The path shards naturally -- every (batch, head, query block) is independent -- so there are exactly two forms:
+
+  A. data-parallel over prompts / batch rows: no collective on the data path (gpt2_generation.shard_prompts,
+     bench.py --gpus N);
+  B. head-sharded (BASELINE config 5): rank g owns heads [g*H/W, (g+1)*H/W) -- column slabs of Q, K, V -- computes its
+     slab of the context vectors, and ONE all-gather of the (B, T, (H/W)*64) slabs rebuilds (B, T, H*64).
+
+`compute` is the single-device attention: `cmhsa.attention_fwd` on a GPU.  The CPU tests pass the oracle instead;
+this module itself never falls back to anything.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+
+def head_slab(t: torch.Tensor, num_heads: int, rank: int, world: int, head_dim: int = 64) -> torch.Tensor:
+    """This rank's heads of a (..., H*head_dim) tensor, as a strided VIEW (the kernel takes row strides)."""
+    if num_heads % world != 0:
+        raise ValueError(f"num_heads ({num_heads}) must be divisible by the number of ranks ({world}); "
+                         "use data-parallel sharding otherwise (GPT2-XL has 25 heads)")
+    per = num_heads // world
+    return t[..., rank * per * head_dim:(rank + 1) * per * head_dim]
+
+
+def head_sharded_attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: int,
+                           compute: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, int], torch.Tensor],
+                           group=None, head_dim: int = 64, gather: bool = True):
+    """Q, K, V: full (B, T, H*head_dim) tensors present on every rank (or at least this rank's head columns valid).
+    Returns the full (B, T, H*head_dim) context on every rank (gather=True), else this rank's slab.
+
+    The all-gather writes into a (W, B, T, slab) buffer (contiguous per-rank slabs, one collective), which is then
+    viewed back to (B, T, H*head_dim); slabs are column blocks of the output, so the permute is a strided copy."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = num_heads // world
+    q, k, v = (head_slab(t, num_heads, rank, world, head_dim) for t in (Q, K, V))
+    slab = compute(q, k, v, per)                                    # (B, T, per*head_dim), contiguous
+    if not gather:
+        return slab
+    slab = slab.contiguous()
+    # output = the W slabs concatenated along dim 0 (the layout every backend's all-gather-into-tensor accepts)
+    flat = torch.empty((world * slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
+    dist.all_gather_into_tensor(flat, slab, group=group)
+    buf = flat.view((world,) + tuple(slab.shape))
+    # (W, B, T, per*hd) -> (B, T, W, per*hd) -> (B, T, H*hd)
+    return buf.movedim(0, -2).reshape(*slab.shape[:-1], world * slab.shape[-1])
+
+
+def batch_sharded_attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: int,
+                            compute: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, int], torch.Tensor],
+                            group=None, gather: bool = False):
+    """Data-parallel over batch rows: rank r takes a contiguous slice of the batch; no collective unless the caller
+    asks for the gathered result (uneven slices are padded to the largest for the gather)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    B = Q.shape[0]
+    base, extra = divmod(B, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    out = compute(Q[lo:hi], K[lo:hi], V[lo:hi], num_heads) if hi > lo else Q.new_empty((0,) + tuple(Q.shape[1:]))
+    if not gather:
+        return out
+    cap = base + (1 if extra else 0)
+    pad = Q.new_zeros((cap,) + tuple(Q.shape[1:]))
+    pad[:hi - lo] = out
+    flat = torch.empty((world * cap,) + tuple(pad.shape[1:]), dtype=pad.dtype, device=pad.device)
+    dist.all_gather_into_tensor(flat, pad, group=group)
+    buf = flat.view((world,) + tuple(pad.shape))
+    parts = [buf[r, :base + (1 if r < extra else 0)] for r in range(world)]
+    return torch.cat(parts, dim=0)
