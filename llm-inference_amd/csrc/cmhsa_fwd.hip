@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "cmhsa.h"
 
@@ -75,7 +76,8 @@ struct Params {
     int num_heads;                      // H
     int bh;                             // batch * H
     int nqb;                            // ceil(N / 32)
-    int xcd_map;                        // 1: blockIdx -> (bh, j) keeps one (b,h) per XCD group
+    int grid_x;                         // gridDim.x: 8 when (b,h)s are pinned to XCDs, else bh (see the kernel)
+    unsigned heads_magic, chain_magic;  // floor((2^32-1) / num_heads), floor((2^32-1) / chain): udiv_magic()
     // packing of query blocks into workgroups (pack_plan()):
     int chain;                          // c: max units any wave processes = ceil(nqb / kWaves)
     int n_paired;                       // R: query blocks 1..R units long are paired n <-> R+1-n
@@ -146,6 +148,14 @@ __device__ __forceinline__ void store_unit(float *lds, int lane, const f32x4 (&r
     }
 }
 
+// floor(n / d) for wave-uniform n, d >= 1 with magic = floor((2^32 - 1) / d): the estimate mulhi(n, magic) is
+// the quotient or one below it for every 32-bit n, so one correction step makes it exact.  A handful of
+// scalar instructions instead of the ~30-instruction float-reciprocal sequence hipcc emits for `/`.
+__device__ __forceinline__ int udiv_magic(int n, int d, unsigned magic) {
+    const unsigned q = __umulhi((unsigned)n, magic);
+    return (int)(q + (((unsigned)n - q * (unsigned)d) >= (unsigned)d ? 1u : 0u));
+}
+
 template <int kWaves>
 __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -154,27 +164,28 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5;      // which k-slot of the MFMA operand this lane feeds
 #ifdef CMHSA_STAMPS
-    const bool stamp_on = g_stamp_buf != nullptr && (int)blockIdx.x == g_stamp_block && lane == 0;
+    const int lin_block = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const bool stamp_on = g_stamp_buf != nullptr && lin_block == g_stamp_block && lane == 0;
     unsigned long long *stamp_ptr = g_stamp_buf + wave * 128;
     int stamp_i = 4;
     STAMP(0);
-    if (g_block_times && threadIdx.x == 0) g_block_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (g_block_times && threadIdx.x == 0) g_block_times[2 * lin_block] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int l31 = lane & 31;       // query (B/C column) or key / d-pair (A row) index of this lane
 
-    // ---- blockIdx -> (batch*head, workgroup j of that head); heaviest workgroups first ----
-    int bh, j;
-    {
-        const int id = blockIdx.x;
-        if (p.xcd_map) {             // blocks b and b+8 share an XCD: give each XCD group its own (b,h)
-            const int xcd = id & 7, t = id >> 3;
-            bh = (t / p.wgs_per_bh) * 8 + xcd;
-            j = t % p.wgs_per_bh;
-        } else {
-            bh = id % p.bh;
-            j = id / p.bh;
-        }
-    }
+    // Pull every kernel argument into SGPRs NOW, with one wait: left alone, hipcc sinks the scalar loads into
+    // the blocks that use them -- five dependent round trips to a cold kernarg segment (~2 k cycles, measured)
+    // before the first global load could be issued.
+    asm volatile("" ::"s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs), "s"(p.v_rs), "s"(p.o_rs));
+    asm volatile("" ::"s"(p.q_bs), "s"(p.k_bs), "s"(p.v_bs), "s"(p.o_bs), "s"(p.seq_len), "s"(p.num_heads), "s"(p.nqb),
+                 "s"(p.grid_x), "s"(p.heads_magic), "s"(p.chain_magic), "s"(p.chain), "s"(p.n_paired), "s"(p.n_alone));
+    STAMP(124);
+
+    // ---- grid -> (batch*head, workgroup j of that head).  Workgroups are dispatched in linear order, x fastest,
+    //      round-robin over the 8 XCDs: with grid = (8, wgs_per_bh, bh/8) every XCD keeps its own (b,h)s (K/V
+    //      stay in that XCD's L2), with grid = (bh, wgs_per_bh, 1) otherwise; either way j = 0 (heaviest) first.
+    const int bh = blockIdx.z * p.grid_x + blockIdx.x;
+    const int j = blockIdx.y;
     // ---- workgroup j -> one or two query blocks ("segments"), this wave -> (segment, local wave index) ----
     int n_a, n_b;                                 // units (= query block index + 1) of segments A and B; 0 = none
     if (j < p.n_alone) {
@@ -186,8 +197,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         n_b = t + 1;
         if (n_b == n_a) n_b = 0;                  // middle block of an odd count: alone with half the waves
     }
-    const int g_a = (n_a + p.chain - 1) / p.chain;             // waves of segment A: [0, g_a)
-    const int g_b = n_b ? (n_b + p.chain - 1) / p.chain : 0;   // waves of segment B: [g_a, g_a + g_b)
+    const int g_a = udiv_magic(n_a + p.chain - 1, p.chain, p.chain_magic);             // waves of segment A: [0, g_a)
+    const int g_b = n_b ? udiv_magic(n_b + p.chain - 1, p.chain, p.chain_magic) : 0;   // of segment B: [g_a, g_a + g_b)
     int n_units, seg_w0, seg_waves, seg;          // units of my query block; first wave / wave count of my segment
     if (wave < g_a) {
         seg = 0; n_units = n_a; seg_w0 = 0; seg_waves = g_a;
@@ -199,9 +210,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     const int wloc = wave - seg_w0;
     const bool active = n_units > 0;
     const int qb = n_units - 1;      // causal early exit: units past the diagonal are never touched (CMHSA.cu:133-136)
-    const int b = bh / p.num_heads, h = bh - b * p.num_heads;
+    const int b = udiv_magic(bh, p.num_heads, p.heads_magic), h = bh - b * p.num_heads;
     const int N = p.seq_len;
-    const int q0 = qb * kQBlock;
 
     const float *qg = p.q + b * p.q_bs + (int64_t)h * kHeadDim;
     const float *kg = p.k + b * p.k_bs + (int64_t)h * kHeadDim;
@@ -211,17 +221,39 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     float *qlds_all = lds + kWaves * kWaveLdsFloats;                   // shared: query block of A | of B,
     float *qlds = qlds_all + seg * kUnitFloats;                        // pre-scaled, K-style swizzle
 
-    // ---- each segment's query block is fetched ONCE: the 8 (or 16) 4-row groups go round-robin over ALL
-    //      waves of the workgroup, are scaled by log2(e)/sqrt(64) and parked in LDS; every wave then reads
-    //      its B-operand fragments from there ----
-    for (int rg = wave; rg < (n_b ? 16 : 8); rg += kWaves) {
-        const int sg = rg >> 3, row = 4 * (rg & 7) + (lane >> 4), chunk = lane & 15;
-        const int sq0 = ((sg ? n_b : n_a) - 1) * kQBlock;
-        const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, sq0, N);
-        f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (row * (int)p.q_rs + chunk * 4) * 4, 0, 0));
-        t *= kScaleLog2;
-        *reinterpret_cast<f32x4 *>(qlds_all + sg * kUnitFloats + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = t;
+    // per-lane byte offsets inside a unit
+    const int sub = lane >> 4, chunk = lane & 15;
+    const int koff = (sub * (int)p.k_rs + chunk * 4) * 4, kstep = 16 * (int)p.k_rs;   // K: coalesced rows -> LDS
+
+    // ---- prologue.  One memory round trip ahead of the first MFMA: every wave requests its first K unit, then
+    //      its share of the query blocks, and waits for both together.  Each segment's query block is fetched
+    //      ONCE: its 8 4-row groups go round-robin over ALL waves of the workgroup, are scaled by
+    //      log2(e)/sqrt(64) and parked in LDS; every wave reads its B-operand fragments from there.
+    //      (Inactive waves and absent segments use zero-record descriptors: no memory touched, no branch.
+    //      Giving the query blocks to waves 0-3 only, so that the barrier opens earlier, measured no faster.) ----
+    f32x4 kst[8];                    // K staging registers (always one unit ahead of LDS)
+    load_unit(unit_rsrc(kg, p.k_rs, wloc * kKeyUnit, N, active), koff, kstep, kst);
+    {
+        constexpr int kQIters = 16 / kWaves;
+        f32x4 qst[kQIters];
+#pragma unroll
+        for (int i = 0; i < kQIters; ++i) {
+            const int rg = wave + i * kWaves, sg = rg >> 3, row = 4 * (rg & 7) + sub;
+            const int sq0 = ((sg && n_b ? n_b : n_a) - 1) * kQBlock;
+            const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, sq0, N, !sg || n_b);
+            qst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (row * (int)p.q_rs + chunk * 4) * 4, 0, 0));
+        }
+        STAMP(121);
+#pragma unroll
+        for (int i = 0; i < kQIters; ++i) {
+            const int rg = wave + i * kWaves, sg = rg >> 3, row = 4 * (rg & 7) + sub;
+            *reinterpret_cast<f32x4 *>(qlds_all + sg * kUnitFloats + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = qst[i] * kScaleLog2;
+        }
     }
+    store_unit<true>(wlds, lane, kst);
+    STAMP(122);
+    __syncthreads();                 // query blocks complete in LDS
+    STAMP(123);
 
     // O^T accumulators.  MFMA row i of o0 / o1 is d = 2i / 2i+1, so that one dwordx2 per lane fetches both
     // A operands of a PV k-step and each half-wave reads one whole contiguous 256-B V row:
@@ -231,9 +263,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     float l_run = 0.f;               // running sum over THIS lane half's keys only (merged at the end)
 
     if (active) {
-        // per-lane byte offsets inside a unit
-        const int sub = lane >> 4, chunk = lane & 15;
-        const int koff = (sub * (int)p.k_rs + chunk * 4) * 4, kstep = 16 * (int)p.k_rs;   // K: coalesced rows -> LDS
         const int vrs4 = (int)p.v_rs * 4;
         const int voff = half * 4 * vrs4 + l31 * 8;                                       // V: straight into MFMA layout
         const float *krow0 = wlds + l31 * kHeadDim;
@@ -242,29 +271,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             return *reinterpret_cast<const f32x4 *>(krow0 + buf * kUnitFloats + (((2 * c + half) ^ sw) << 2));
         };
 
-        // ---- prologue: K(u0) -> regs -> LDS[0]; Q -> regs; K(u1) prefetch.  All per-lane load offsets are
-        //      computed once: VALU instructions are NOT free beside fp32 MFMAs (they share the SIMD's fp32
-        //      datapath: measured cost = sum of both), so the main loop carries as few as possible. ----
+        // All per-lane load offsets are computed once: VALU instructions are NOT free beside fp32 MFMAs (they
+        // share the SIMD's fp32 datapath: measured cost = sum of both), so the main loop carries as few as possible.
         int koffs[8], voffs[16];
 #pragma unroll
         for (int i = 0; i < 8; ++i) koffs[i] = koff + i * kstep;
 #pragma unroll
         for (int r = 0; r < 16; ++r) voffs[r] = voff + acc_row(r) * vrs4;
-        f32x4 kst[8];                // K staging registers (always one unit ahead of LDS)
         f32x2 vreg[16];              // V of the current unit, MFMA A-operand layout: [k-step r] = {d even, d odd}
-        // Only what the first QK chain needs (K(u0), and the Q block above) is requested before the barrier:
-        // a CU's L1 fills at 64 B/clk, and every byte queued ahead of another wave's K(u0) delays the
-        // whole workgroup's start.  V(u0) and K(u1) follow behind the barrier.
-        load_unit(unit_rsrc(kg, p.k_rs, wloc * kKeyUnit, N), koff, kstep, kst);
-        store_unit<true>(wlds, lane, kst);
-        __syncthreads();             // Q block complete in LDS (every wave of the workgroup reaches this)
-        {
-            const __amdgpu_buffer_rsrc_t vsrc0 = unit_rsrc(vg, p.v_rs, wloc * kKeyUnit, N);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                vreg[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc0, voffs[r], 0, 0));
-        }
-        load_unit(unit_rsrc(kg, p.k_rs, (wloc + seg_waves) * kKeyUnit, N, wloc + seg_waves < n_units), koff, kstep, kst);
         float qf[32];                // Q^T fragment: B operand of S^T = K Q^T; k-step 4c+j uses d = 8c + 4*half + j
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -276,18 +290,32 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         int cur = 0;
         STAMP(1);
 
-        for (int u = wloc; u < n_units; u += seg_waves) {
+        // One unit = QK chain, softmax, PV chain.  `first` (compile time): the wave's first unit, whose QK chain
+        // also carries the loads the steady state issues one unit ahead -- V(u) and K(u + seg_waves) -- so that
+        // the first MFMA does not queue behind 24 more buffer loads per wave (a CU's L1 serves 64 B/clk).
+        auto unit = [&](const int u, auto first) __attribute__((always_inline)) {
+            constexpr bool kFirst = decltype(first)::value;
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i);
 #endif
             // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] : 32 chained MFMAs.  K fragments are read
             //      two steps (512 MFMA cycles) ahead. ----
             f32x16 s = {0};
+            __amdgpu_buffer_rsrc_t vsrc0, ksrc1;
+            if constexpr (kFirst) {
+                vsrc0 = unit_rsrc(vg, p.v_rs, u * kKeyUnit, N);
+                ksrc1 = unit_rsrc(kg, p.k_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < n_units);
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const f32x4 kk = kcur;
                 kcur = knext;
                 if (c + 2 < 8) knext = kfrag(cur, c + 2);
+                if constexpr (kFirst) {
+                    vreg[2 * c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc0, voffs[2 * c], 0, 0));
+                    vreg[2 * c + 1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc0, voffs[2 * c + 1], 0, 0));
+                    kst[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ksrc1, koffs[c], 0, 0));
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -376,10 +404,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             stamp_i += 4;
 #endif
             cur ^= 1;
-        }
+        };
+
+        unit(wloc, std::true_type{});            // every active wave owns at least one unit (wloc < seg_waves <= n_units)
+        for (int u = wloc + seg_waves; u < n_units; u += seg_waves) unit(u, std::false_type{});
         l_run = xhalf_sum(l_run);
-    } else {
-        __syncthreads();             // pairs with the Q-block barrier of the active waves
     }
 #ifdef CMHSA_STAMPS
     STAMP(2);
@@ -452,7 +481,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 std::atomic<int> g_attr_set[2][64];  // per variant and device: dynamic-LDS limit raised once, not per call
 
 template <int kWaves>
-hipError_t launch(const Params &p, int64_t blocks, void *stream) {
+hipError_t launch(const Params &p, dim3 grid, void *stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -463,7 +492,7 @@ hipError_t launch(const Params &p, int64_t blocks, void *stream) {
         if (e != hipSuccess) return e;
         if (flag) flag->store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(cmhsa_fwd_kernel<kWaves>, dim3((unsigned)blocks), dim3(kWaves * 64), lds_bytes(kWaves),
+    hipLaunchKernelGGL(cmhsa_fwd_kernel<kWaves>, grid, dim3(kWaves * 64), lds_bytes(kWaves),
                        static_cast<hipStream_t>(stream), p);
     return hipSuccess;
 }
@@ -544,8 +573,12 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
 
     const int waves = choose_waves(bh, (int)nqb);
     const PackPlan pl = pack_plan((int)nqb, waves);
-    const int64_t blocks = bh * pl.wgs_per_bh;
-    if (blocks > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    // grid = (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8
+    // or too large for gridDim.z.  HIP limits: y, z <= 65535, and x * threads < 2^32.
+    const bool xcd_map = bh % 8 == 0 && bh / 8 <= 65535;
+    const dim3 grid(xcd_map ? 8u : (unsigned)bh, (unsigned)pl.wgs_per_bh, xcd_map ? (unsigned)(bh / 8) : 1u);
+    if (pl.wgs_per_bh > 65535 || (int64_t)grid.x * (waves * 64) >= (1LL << 32) ||
+        bh * pl.wgs_per_bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
 
     Params p;
     p.q = q; p.k = k; p.v = v; p.o = o;
@@ -555,10 +588,12 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     p.num_heads = num_heads;
     p.bh = (int)bh;
     p.nqb = (int)nqb;
-    p.xcd_map = (bh % 8 == 0) ? 1 : 0;
+    p.grid_x = (int)grid.x;
+    p.heads_magic = 0xffffffffu / (unsigned)num_heads;
+    p.chain_magic = 0xffffffffu / (unsigned)pl.chain;
     p.chain = pl.chain; p.n_paired = pl.n_paired; p.n_alone = pl.n_alone; p.wgs_per_bh = pl.wgs_per_bh;
 
-    hipError_t e = waves == 8 ? launch<8>(p, blocks, stream) : launch<4>(p, blocks, stream);
+    hipError_t e = waves == 8 ? launch<8>(p, grid, stream) : launch<4>(p, grid, stream);
     if (e != hipSuccess) return (int)e;
     e = hipGetLastError();                 // launch-configuration errors only; no synchronisation (CMHSA.cu:450)
     return e == hipSuccess ? CMHSA_OK : (int)e;

@@ -89,7 +89,7 @@ int main(int argc, char **argv) {
             const unsigned long long *p = &hs[w * 128];
             printf("wave %d: entry %lld  q_loaded %lld  loop_end %lld  done %lld | units (top, qk_start, qk_issued, pv_start):\n", w,
                    (long long)(p[0] - t0), (long long)(p[1] - t0), (long long)(p[2] - t0), (long long)(p[3] - t0));
-            printf("    merge: ml_published %lld  images_written %lld  after_barrier %lld\n", (long long)(p[120] - t0), (long long)(p[121] - t0), (long long)(p[122] - t0));
+            printf("    merge: ml_published %lld | prologue: kernargs %lld  k0_issued %lld  k0_in_lds %lld  after_barrier %lld\n", (long long)(p[120] - t0), (long long)(p[124] - t0), (long long)(p[121] - t0), (long long)(p[122] - t0), (long long)(p[123] - t0));
             for (int i = 4; i + 3 < 120 && p[i]; i += 4)
                 printf("    %lld %lld %lld %lld\n", (long long)(p[i] - t0), (long long)(p[i + 1] - t0), (long long)(p[i + 2] - t0), (long long)(p[i + 3] - t0));
         }
