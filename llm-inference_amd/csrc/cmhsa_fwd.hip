@@ -4,17 +4,23 @@
 // launcher (reference torch_extensions/causal_multihead_self_attention/
 // causal_multihead_self_attention.cu:64-462, "CMHSA.cu" below) behind the C ABI of include/cmhsa.h.
 //
-// Decomposition (see DESIGN.md for the why):
-//   * one workgroup (4 wave64s, one per SIMD) = one 32-row query block of one (batch, head);
-//   * the KV range [0, q_block_end) is cut into 32-key units; wave w takes units w, w+4, ...
-//     (split-KV inside the workgroup), so even the T=1024, B=1 shape fills 256 CUs;
-//   * S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x2_f32: with S^T the query sits on the
-//     lane, so softmax statistics are per-lane scalars and the S^T accumulator registers are,
-//     as they stand, the B operand of the PV product (no LDS round trip, no lane shuffles);
-//   * each wave stages its own K/V units in a private, double-buffered LDS region
-//     (K XOR-swizzled for conflict-free ds_read_b128), so the main loop has no barrier at all;
-//   * online softmax in the log2 domain (Q pre-scaled by log2(e)/sqrt(64)), normalisation
-//     deferred to the very end; the 4 partial (m, l, O) triples are merged through LDS.
+// Decomposition (see DESIGN.md section 3 for the why and the measurements):
+//   * work item = one 32-row query block of one (batch, head); its KV range [0, q_block_end) is cut into
+//     32-key units (causal early exit: nothing past the diagonal is touched, only the diagonal unit is masked);
+//   * a workgroup has W = 8 (one per CU) or 4 (two per CU) wave64s and holds ONE long query block or a PAIR
+//     of a long and a short one (pack_plan(): every wave gets at most ceil(nqb/W) units); the waves of a
+//     block split its units round-robin (split-KV inside the workgroup), so even B=1, T=1024 fills the chip
+//     with one round of equally long workgroups;
+//   * S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x2_f32: with S^T the query sits on the lane, so
+//     softmax statistics are per-lane scalars and the S^T accumulator registers are, as they stand, the B
+//     operand of the PV product (no LDS round trip, no lane shuffles);
+//   * K: coalesced buffer loads -> staging registers -> the wave's private, double-buffered, XOR-swizzled
+//     LDS unit -> ds_read_b128 fragments; V: straight from global into the MFMA A-operand layout, one
+//     unit ahead; the query block is fetched once per workgroup into shared LDS.  The main loop has no
+//     barrier and no branch inside the MFMA chains;
+//   * online softmax in the log2 domain (Q pre-scaled by log2(e)/sqrt(64)), lazy rescale, normalisation
+//     deferred to the merge: the partial (m, l, O) of a block's waves are combined through LDS behind the
+//     kernel's second and last barrier.
 //
 // Function computed per (batch b, head h), exactly CMHSA.cu:64-405 / the naive formula of
 // reference causal_self_attention.py:173-194:
