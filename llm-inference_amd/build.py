@@ -3,7 +3,7 @@
     python llm-inference_amd/build.py [--force]
 
 Produces (all git-ignored, all shipped to the GPU box by gpurun):
-  llm-inference_amd/lib/libcmhsa_hip.so                       hand-written gfx950 kernels + C ABI
+  llm-inference_amd/lib/libcmhsa_hip.so                       hand-written gfx950 kernels + C ABI (attention, GELU)
   llm-inference_amd/causal_multihead_self_attention.<abi>.so  torch binding / importable module
 
 The reference builds its extension with torch.utils.cpp_extension.CUDAExtension
@@ -44,16 +44,17 @@ def _run(cmd: list[str]) -> None:
 
 
 def build_kernel_lib(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, "cmhsa_fwd.hip"), os.path.join(INCLUDE, "cmhsa.h")]
-    if force or _stale(KERNEL_LIB, srcs):
+    hip = [os.path.join(CSRC, "cmhsa_fwd.hip"), os.path.join(CSRC, "gelu_fwd.hip")]
+    headers = [os.path.join(INCLUDE, "cmhsa.h"), os.path.join(INCLUDE, "gpt2_gelu.h")]
+    if force or _stale(KERNEL_LIB, hip + headers):
         os.makedirs(LIBDIR, exist_ok=True)
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-I" + INCLUDE, "-o", KERNEL_LIB, srcs[0]])
+              "-I" + INCLUDE, "-o", KERNEL_LIB, *hip])
     return KERNEL_LIB
 
 
 def build_torch_binding(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, "torch_binding.cpp"), os.path.join(INCLUDE, "cmhsa.h"), KERNEL_LIB]
+    srcs = [os.path.join(CSRC, "torch_binding.cpp"), os.path.join(INCLUDE, "cmhsa.h"), os.path.join(INCLUDE, "gpt2_gelu.h"), KERNEL_LIB]
     if force or _stale(EXT_PATH, srcs):
         import torch
         from torch.utils import cpp_extension

@@ -19,13 +19,15 @@ import torch  # must be imported BEFORE the library: both must share torch's lib
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcmhsa_hip.so")
 
-# every symbol include/cmhsa.h declares; tests/test_abi.py checks the header against this list
+# every symbol include/*.h declares; tests/test_abi.py checks the headers against this list
 EXPORTED_SYMBOLS = (
     "cmhsa_status_string",
     "cmhsa_version",
     "cmhsa_fp32_fwd",
     "cmhsa_fp32_fwd_2d",
     "cmhsa_algorithmic_flops",
+    "gpt2_gelu_tanh_f32_fwd",        # include/gpt2_gelu.h
+    "gpt2_gelu_algorithmic_bytes",
 )
 
 CMHSA_OK = 0
@@ -65,6 +67,10 @@ def load_library() -> ctypes.CDLL:
     lib.cmhsa_fp32_fwd_2d.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp]
     lib.cmhsa_algorithmic_flops.restype = ctypes.c_double
     lib.cmhsa_algorithmic_flops.argtypes = [i32, i32, i32, i32]
+    lib.gpt2_gelu_tanh_f32_fwd.restype = i32
+    lib.gpt2_gelu_tanh_f32_fwd.argtypes = [vp, vp, i64, vp]
+    lib.gpt2_gelu_algorithmic_bytes.restype = ctypes.c_double
+    lib.gpt2_gelu_algorithmic_bytes.argtypes = [i64]
     _lib = lib
     return lib
 
@@ -123,6 +129,25 @@ def attention_fwd(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: 
         stream = torch.cuda.current_stream(Q.device).cuda_stream
         rc = attention_fwd_raw(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), rs, bs,
                                B, N, num_heads, d_model // num_heads, stream)
+    if rc != CMHSA_OK:
+        raise CmhsaError(rc, status_string(rc))
+    return out
+
+
+def gelu_tanh_fwd(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Fused tanh-GELU (reference gelu.py:8-12) through the C ABI of include/gpt2_gelu.h, on torch's current
+    stream.  x: contiguous fp32 device tensor of any shape; `out` may be x itself (in place)."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise ValueError("x must be a float32 CUDA tensor")
+    if not x.is_contiguous():
+        raise ValueError("x must be contiguous")
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != x.dtype or out.device != x.device or not out.is_contiguous():
+        raise ValueError("out must match x (shape, dtype, device) and be contiguous")
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        rc = load_library().gpt2_gelu_tanh_f32_fwd(x.data_ptr(), out.data_ptr(), x.numel(), ctypes.c_void_p(stream))
     if rc != CMHSA_OK:
         raise CmhsaError(rc, status_string(rc))
     return out

@@ -23,6 +23,7 @@
 #include <torch/library.h>
 
 #include "cmhsa.h"
+#include "gpt2_gelu.h"
 
 namespace causal_multihead_self_attention {
 
@@ -70,12 +71,29 @@ at::Tensor causal_multihead_self_attention_torch(at::Tensor Q, at::Tensor K, at:
     return output;
 }
 
+// Fused tanh-GELU (reference gelu.py:4-12 is a plain nn.Module with no extension op, so
+// this op has no reference schema to mirror): any-shape contiguous fp32 device tensor in, new tensor out.
+at::Tensor gelu_tanh(at::Tensor x) {
+    TORCH_CHECK(x.is_cuda(), "x must be a CUDA tensor");
+    TORCH_CHECK(x.dtype() == at::kFloat, "x must be float32");
+    const at::Tensor xc = x.contiguous();
+    at::Tensor y = at::empty_like(xc);
+    if (y.numel() == 0) return y;
+    const c10::hip::HIPGuard guard(x.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(x.device().index()).stream();
+    const int rc = gpt2_gelu_tanh_f32_fwd(xc.data_ptr<float>(), y.data_ptr<float>(), xc.numel(), stream);
+    TORCH_CHECK(rc == CMHSA_OK, "gpt2_gelu_tanh_f32_fwd failed (", rc, "): ", cmhsa_status_string(rc));
+    return y;
+}
+
 TORCH_LIBRARY(causal_multihead_self_attention, m) {
     m.def("causal_multihead_self_attention_torch(Tensor Q, Tensor K, Tensor V, int num_heads) -> Tensor");
+    m.def("gelu_tanh(Tensor x) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
     m.impl("causal_multihead_self_attention_torch", &causal_multihead_self_attention_torch);
+    m.impl("gelu_tanh", &gelu_tanh);
 }
 
 }  // namespace causal_multihead_self_attention

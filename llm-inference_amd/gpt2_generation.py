@@ -33,6 +33,7 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 from causal_self_attention import CausalSelfAttention, ScaledDotProductAttentionBackend  # noqa: E402
+from gelu import GELU  # noqa: E402
 
 # "Hello, I'm a language model," under the GPT-2 BPE (reference gpt2.py:143).  From memory, NOT re-verified here:
 # tiktoken is not installed in this image and would need the network for its BPE files.
@@ -48,17 +49,14 @@ GPT2_CONFIGS = {             # reference gpt2.py:59-71
 COMMON = dict(vocab_size=50257, context_length=1024, drop_rate=0.1, qkv_bias=True)
 
 
-def tanh_gelu(x: torch.Tensor) -> torch.Tensor:
-    """The reference's GELU, same expression tree (gelu.py:9-12)."""
-    return 0.5 * x * (1 + torch.tanh(torch.sqrt(torch.tensor(2.0 / torch.pi)) * (x + 0.44715 * torch.pow(x, 3))))
-
 
 class Block(nn.Module):
     """Pre-LN block: x + attn(LN(x)); x + mlp(LN(x)) (transformer_block.py:26-39); dropouts are identity in eval()."""
 
-    def __init__(self, cfg: dict, backend: ScaledDotProductAttentionBackend):
+    def __init__(self, cfg: dict, backend: ScaledDotProductAttentionBackend, fused_gelu: bool = False):
         super().__init__()
         d = cfg["emb_dim"]
+        self.gelu = GELU(fused=fused_gelu)           # reference feed_forward.py:14; fused = one HIP launch instead of eight
         self.first_layer_norm = nn.LayerNorm(d)
         self.attention = CausalSelfAttention(d_in=d, d_out=d, max_context_length=cfg["context_length"],
                                              p_dropout=cfg["drop_rate"], num_heads=cfg["n_heads"],
@@ -69,27 +67,32 @@ class Block(nn.Module):
 
     def forward(self, x):
         x = x + self.attention(self.first_layer_norm(x))
-        return x + self.mlp_out(tanh_gelu(self.mlp_in(self.second_layer_norm(x))))
+        return x + self.mlp_out(self.gelu(self.mlp_in(self.second_layer_norm(x))))
 
 
 class GPT2Model(nn.Module):
-    def __init__(self, cfg: dict, backend: ScaledDotProductAttentionBackend, last_position_only: bool = False):
+    def __init__(self, cfg: dict, backend: ScaledDotProductAttentionBackend, last_position_only: bool = False,
+                 fused_gelu: bool = False):
         super().__init__()
         self.cfg = cfg
         self.last_position_only = last_position_only      # opt-in; default = reference behaviour
         self.token_embeddings = nn.Embedding(cfg["vocab_size"], cfg["emb_dim"])
         self.positional_embeddings = nn.Embedding(cfg["context_length"], cfg["emb_dim"])
-        self.blocks = nn.ModuleList(Block(cfg, backend) for _ in range(cfg["n_layers"]))
+        self.blocks = nn.ModuleList(Block(cfg, backend, fused_gelu) for _ in range(cfg["n_layers"]))
         self.layer_norm = nn.LayerNorm(cfg["emb_dim"])
         self.output_layer = nn.Linear(cfg["emb_dim"], cfg["vocab_size"], bias=False)
 
-    def forward(self, tokens: torch.Tensor) -> torch.Tensor:
-        """tokens (B, T) -> logits (B, T, vocab) (reference gpt2.py:41-45), or (B, 1, vocab) with last_position_only."""
+    def hidden_states(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens (B, T) -> residual stream (B, T, emb_dim) after the last block, before the final LayerNorm."""
         n = tokens.shape[1]
         x = self.token_embeddings(tokens) + self.positional_embeddings(torch.arange(n, device=tokens.device))
         for blk in self.blocks:
             x = blk(x)
-        x = self.layer_norm(x)
+        return x
+
+    def forward(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens (B, T) -> logits (B, T, vocab) (reference gpt2.py:41-45), or (B, 1, vocab) with last_position_only."""
+        x = self.layer_norm(self.hidden_states(tokens))
         if self.last_position_only:
             x = x[:, -1:, :]
         return self.output_layer(x)
@@ -122,10 +125,10 @@ class GPT2Model(nn.Module):
 
 
 def build_model(name: str, backend: ScaledDotProductAttentionBackend, device, weights: str | None = None, seed: int = 0,
-                last_position_only: bool = False, overrides: dict | None = None) -> GPT2Model:
+                last_position_only: bool = False, overrides: dict | None = None, fused_gelu: bool = False) -> GPT2Model:
     cfg = {**COMMON, **GPT2_CONFIGS[name], **(overrides or {})}
     torch.manual_seed(seed)                       # seeded random weights unless a local checkpoint is given
-    model = GPT2Model(cfg, backend, last_position_only)
+    model = GPT2Model(cfg, backend, last_position_only, fused_gelu)
     if weights:
         model.load_hf_safetensors(weights)
     return model.eval().to(device)
@@ -160,6 +163,111 @@ def greedy_generate(model: nn.Module, prompt_ids, max_tokens: int, eos_token: in
     return out
 
 
+class BucketedGreedyGenerator:
+    """Greedy decoding without a host round trip per token.
+
+    The reference loop (sampler.py:14-19) re-runs the whole model on a sequence that grows by one token, reads the
+    arg-max back with `.item()` and builds a new tensor: ~200 small launches and one sync per token, so a 512-token
+    generation is launch-bound.  Here the tokens live in ONE static (B, max_tokens) device buffer and a step is a
+    fixed sequence of device operations over the first L positions, L = the current length rounded up to `bucket`:
+
+        hidden_states(tokens[:, :L]) -> row `pos` -> final LayerNorm -> LM head -> argmax -> tokens[:, pos+1]; pos += 1
+
+    Every operation of the model is per-position except attention, which is causal, so the padded positions
+    > pos cannot influence row `pos`: the step computes the reference's logits[0, -1, :] (only that row of the LM
+    head).  With a fixed shape per bucket the step is captured once per bucket as a HIP graph
+    (`use_graphs=True`, torch.cuda.CUDAGraph = hipGraph on ROCm) and replayed: max_tokens/bucket graphs in all, one
+    launch per token.  `use_graphs=False` runs the identical step eagerly (CPU tests, debugging).
+
+    EOS: a finished row keeps receiving EOS; the host looks at the `done` flags every `check_every` steps only,
+    and rows are trimmed after their first generated EOS, so the returned tokens equal greedy_generate()'s."""
+
+    def __init__(self, model: "GPT2Model", batch: int, max_tokens: int, bucket: int = 64, eos_token: int = EOS_TOKEN,
+                 use_graphs: bool = True, check_every: int = 32, device=None):
+        self.model, self.batch, self.max_tokens, self.bucket, self.eos = model, batch, max_tokens, bucket, eos_token
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        self.use_graphs = use_graphs
+        if use_graphs and self.device.type != "cuda":
+            raise RuntimeError("HIP graphs need a GPU; pass use_graphs=False for the eager form of the same step")
+        if max_tokens > model.cfg["context_length"]:
+            raise ValueError("max_tokens exceeds the model's context length")
+        self.check_every = check_every
+        self.cap = -(-max_tokens // bucket) * bucket                  # buffer length: whole buckets
+        self.cap = min(self.cap, model.cfg["context_length"])
+        self.tokens = torch.zeros((batch, self.cap), dtype=torch.long, device=self.device)
+        self.pos = torch.zeros((1,), dtype=torch.long, device=self.device)     # index of the last valid token
+        self.done = torch.zeros((batch,), dtype=torch.bool, device=self.device)
+        self._graphs: dict[int, "torch.cuda.CUDAGraph"] = {}
+        self._pool = None
+
+    def bucket_len(self, length: int) -> int:
+        return min(-(-length // self.bucket) * self.bucket, self.cap)
+
+    @torch.no_grad()
+    def _step(self, L: int) -> None:
+        m = self.model
+        x = m.hidden_states(self.tokens[:, :L])
+        h = m.layer_norm(x.index_select(1, self.pos))                 # (B, 1, emb_dim): LayerNorm is per position
+        nxt = torch.argmax(m.output_layer(h)[:, 0, :], dim=-1)        # first max wins, as in the reference
+        nxt = torch.where(self.done, torch.full_like(nxt, self.eos), nxt)
+        self.done.logical_or_(nxt == self.eos)
+        self.pos.add_(1)
+        self.tokens.index_copy_(1, self.pos, nxt.unsqueeze(1))
+
+    def _graph_for(self, L: int) -> "torch.cuda.CUDAGraph":
+        g = self._graphs.get(L)
+        if g is None:
+            saved = (self.tokens.clone(), self.pos.clone(), self.done.clone())
+            side = torch.cuda.Stream(self.device)                     # warm-up off the capture stream: lazy inits,
+            side.wait_stream(torch.cuda.current_stream(self.device))  # GEMM workspace, LDS attribute of the kernel
+            with torch.cuda.stream(side):
+                self._step(L)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._pool):                # one memory pool: the graphs never overlap
+                self._step(L)
+            if self._pool is None:
+                self._pool = g.pool()
+            for dst, src in zip((self.tokens, self.pos, self.done), saved):
+                dst.copy_(src)                                        # the warm-up step advanced the state: undo
+            self._graphs[L] = g
+        return g
+
+    @torch.no_grad()
+    def generate(self, prompt_ids) -> list[list[int]]:
+        prompt = torch.as_tensor(prompt_ids, dtype=torch.long, device=self.device)
+        if prompt.dim() == 1:
+            prompt = prompt.unsqueeze(0)
+        if prompt.shape[0] != self.batch:
+            raise ValueError(f"generator was built for batch {self.batch}, got {prompt.shape[0]} prompts")
+        plen = prompt.shape[1]
+        if plen < 1 or plen > self.max_tokens:
+            raise ValueError("prompt length must be in [1, max_tokens]")
+        self.tokens.zero_()
+        self.tokens[:, :plen] = prompt
+        self.pos.fill_(plen - 1)
+        self.done.zero_()
+        length = plen
+        while length < self.max_tokens:
+            L = self.bucket_len(length)
+            if self.use_graphs:
+                self._graph_for(L).replay()
+            else:
+                self._step(L)
+            length += 1
+            if (length - plen) % self.check_every == 0 and bool(self.done.all()):
+                break                                                  # the reference stops at EOS (sampler.py:14)
+        out = []
+        for row in self.tokens[:, :length].tolist():
+            cut = len(row)
+            for i in range(plen, len(row)):
+                if row[i] == self.eos:
+                    cut = i + 1
+                    break
+            out.append(row[:cut])
+        return out
+
+
 @dataclass
 class GenerationTiming:
     first_run_seconds: float
@@ -168,19 +276,23 @@ class GenerationTiming:
     tokens: list
 
 
-def time_greedy_generation(model, prompt_ids, max_tokens: int, device) -> GenerationTiming:
-    """Mirror of reference gpt2.py:104-134: warm-up run of prompt+3 tokens, then the timed run."""
+def time_greedy_generation(model, prompt_ids, max_tokens: int, device, generator: "BucketedGreedyGenerator | None" = None) -> GenerationTiming:
+    """Mirror of reference gpt2.py:104-134: warm-up run of prompt+3 tokens, then the timed run.  With a
+    BucketedGreedyGenerator the warm-up is one full generation instead (it captures the graphs, the analogue of the
+    reference's warm-up paying for lazy initialisation), and the timed run replays them."""
     plen = len(prompt_ids[0]) if isinstance(prompt_ids[0], (list, tuple)) else len(prompt_ids)
     sync = (lambda: torch.cuda.synchronize(device)) if torch.device(device).type == "cuda" else (lambda: None)
+    run = (lambda n: generator.generate(prompt_ids)) if generator is not None else \
+          (lambda n: greedy_generate(model, prompt_ids, n, device=device))
     t0 = time.perf_counter_ns()
-    greedy_generate(model, prompt_ids, plen + 3, device=device)
+    run(plen + 3)
     sync()
     first = (time.perf_counter_ns() - t0) / 1e9
     torch.manual_seed(0)
     if torch.device(device).type == "cuda":
         torch.cuda.reset_peak_memory_stats(device)
     t0 = time.perf_counter_ns()
-    toks = greedy_generate(model, prompt_ids, max_tokens, device=device)
+    toks = run(max_tokens)
     sync()
     second = (time.perf_counter_ns() - t0) / 1e9
     peak = torch.cuda.max_memory_allocated(device) if torch.device(device).type == "cuda" else 0
@@ -204,6 +316,9 @@ def main() -> None:
     ap.add_argument("--weights", default=None, help="local HF model.safetensors; default: seeded random weights")
     ap.add_argument("--last-position-lm-head", action="store_true")
     ap.add_argument("--threads", type=int, default=0, help="CPU threads for --device cpu (0 = all cores)")
+    ap.add_argument("--graphs", action="store_true", help="bucketed static-buffer loop replayed as HIP graphs (one launch per token)")
+    ap.add_argument("--bucket", type=int, default=64)
+    ap.add_argument("--fused-gelu", action="store_true", help="GELU as one HIP launch (include/gpt2_gelu.h) instead of eight torch ops")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,12 +339,14 @@ def main() -> None:
         dist.init_process_group("nccl" if device.type == "cuda" else "gloo",
                                 **({"device_id": device} if device.type == "cuda" else {}))
 
-    model = build_model(args.model, backend, device, weights=args.weights, last_position_only=args.last_position_lm_head)
+    model = build_model(args.model, backend, device, weights=args.weights, last_position_only=args.last_position_lm_head,
+                        fused_gelu=args.fused_gelu)
     mine = shard_prompts(args.batch, rank, world)
     prompts = [list(REFERENCE_PROMPT_IDS) for _ in mine]
     if world > 1:
         dist.barrier()
-    timing = time_greedy_generation(model, prompts, args.max_tokens, device) if prompts else GenerationTiming(0, 0, 0, [])
+    gen = BucketedGreedyGenerator(model, len(prompts), args.max_tokens, bucket=args.bucket, device=device) if args.graphs and prompts else None
+    timing = time_greedy_generation(model, prompts, args.max_tokens, device, gen) if prompts else GenerationTiming(0, 0, 0, [])
     seconds = timing.second_run_seconds
     generated = sum(len(t) - len(REFERENCE_PROMPT_IDS) for t in timing.tokens)
     if world > 1:
@@ -246,7 +363,7 @@ def main() -> None:
         tokens = timing.tokens
     if rank == 0:
         print(json.dumps({
-            "model": args.model, "backend": args.backend, "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
+            "model": args.model, "backend": args.backend, "loop": f"hip graphs, bucket {args.bucket}" if args.graphs else "eager (reference loop)", "gelu": "fused HIP kernel" if args.fused_gelu else "reference expression (8 torch ops)", "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
             "cpu_threads": torch.get_num_threads() if device.type == "cpu" else None,
             "weights": args.weights or "random (torch.manual_seed(0))", "prompts": args.batch, "max_tokens": args.max_tokens,
             "warmup_seconds": round(timing.first_run_seconds, 4), "seconds": round(seconds, 4),

@@ -1,5 +1,5 @@
 """CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
-include/cmhsa.h declares, and its host-only entry points behave.  No kernel is launched here."""
+include/*.h declare, and its host-only entry points behave.  No kernel is launched here."""
 import ctypes
 import os
 import re
@@ -9,13 +9,15 @@ import pytest
 import cmhsa
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "cmhsa.h")
+HEADERS = sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
 
 
 def _declared_functions():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cmhsa_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in HEADERS:
+        text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+        names |= set(re.findall(r"\b((?:cmhsa|gpt2)_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_and_python_symbol_lists_agree():

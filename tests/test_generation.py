@@ -75,6 +75,56 @@ def test_batch_equals_single_on_cpu():
     assert three == one * 3
 
 
+def test_bucketed_loop_equals_reference_loop_on_cpu():
+    """The static-buffer, padded-to-bucket step computes the reference's logits[0, -1, :] (causality: padded
+    positions cannot reach row `pos`), so the tokens equal greedy_generate()'s; eager form of the graph body."""
+    m = gen.build_model("gpt2", Backend.NAIVE_PYTORCH, "cpu", overrides=TINY, seed=5)
+    for prompt, max_tokens, bucket in (([5, 6, 7], 40, 16), ([1, 2, 3, 4, 5], 33, 8), ([9], 64, 64), ([3] * 16, 17, 16)):
+        ref = gen.greedy_generate(m, prompt, max_tokens=max_tokens, eos_token=96)
+        g = gen.BucketedGreedyGenerator(m, 1, max_tokens, bucket=bucket, eos_token=96, use_graphs=False)
+        assert g.generate(prompt) == ref
+        assert g.generate(prompt) == ref             # the generator is reusable: state is reset per call
+    ref2 = gen.greedy_generate(m, [[5, 6, 7], [7, 6, 5]], max_tokens=30, eos_token=96)
+    g2 = gen.BucketedGreedyGenerator(m, 2, 30, bucket=16, eos_token=96, use_graphs=False)
+    assert g2.generate([[5, 6, 7], [7, 6, 5]]) == ref2
+
+
+def test_bucketed_loop_eos_semantics():
+    """EOS handling of the bucketed loop with a scripted LM head: finished rows keep EOS, output is trimmed after the
+    first generated EOS, the host only looks at the flags every `check_every` steps."""
+
+    class Scripted(nn.Module):
+        def __init__(self, script, vocab=20, d=8):
+            super().__init__()
+            self.cfg = dict(context_length=64)
+            self.script, self.vocab, self.d, self.calls = script, vocab, d, 0
+            self.layer_norm = nn.Identity()
+            self.dummy = nn.Parameter(torch.zeros(1))
+
+        def hidden_states(self, tokens):
+            B, T = tokens.shape
+            x = torch.zeros(B, T, self.vocab)
+            for b in range(B):
+                x[b, :, self.script[b][min(self.calls, len(self.script[b]) - 1)]] = 5.0
+            self.calls += 1
+            return x
+
+        def output_layer(self, h):
+            return h
+
+    m = Scripted([[1, 0, 5, 5, 5, 5, 5, 5], [2, 3, 4, 0, 5, 5, 5, 5]])
+    g = gen.BucketedGreedyGenerator(m, 2, 12, bucket=4, eos_token=0, use_graphs=False, check_every=2, device="cpu")
+    assert g.generate([[9, 9], [8, 8]]) == [[9, 9, 1, 0], [8, 8, 2, 3, 4, 0]]
+    assert m.calls == 4                              # all rows done after 4 steps, seen at the step-4 check
+    m2 = Scripted([[4, 7, 7, 7, 7, 7, 7, 7, 7, 7]])
+    g = gen.BucketedGreedyGenerator(m2, 1, 6, bucket=4, eos_token=0, use_graphs=False, device="cpu")
+    assert g.generate([9, 9, 9]) == [[9, 9, 9, 4, 7, 7]]      # total length, not new tokens
+    with pytest.raises(ValueError):
+        g.generate([[1, 2], [3, 4]])
+    with pytest.raises(RuntimeError):
+        gen.BucketedGreedyGenerator(m2, 1, 6, use_graphs=True, device="cpu")
+
+
 def test_local_hf_checkpoint_loader(tmp_path):
     """HF GPT-2 layout: Conv1D weights stored (in, out) -> transposed on load; LM head tied to wte
     (reference gpt2.py:16-25, :47-56)."""
@@ -135,3 +185,25 @@ def test_batched_generation_matches_single_on_gpu(gpu_device):
     one = gen.greedy_generate(hip, list(gen.REFERENCE_PROMPT_IDS), 96)
     four = gen.greedy_generate(hip, [list(gen.REFERENCE_PROMPT_IDS)] * 4, 96)
     assert four == one * 4
+
+
+@pytest.mark.gpu
+def test_hip_graph_generation_identical_to_reference_loop_on_gpu(gpu_device):
+    """the bucketed loop replayed as HIP graphs (one launch per token, no per-token sync) must
+    produce the tokens of the reference loop -- checked against BOTH eager backends, 512 total tokens, B=1 and B=3."""
+    naive = gen.build_model("gpt2", Backend.NAIVE_PYTORCH, gpu_device, seed=0)
+    hip = gen.build_model("gpt2", Backend.CUSTOM_CUDA, gpu_device, seed=0)
+    prompt = list(gen.REFERENCE_PROMPT_IDS)
+    ref = gen.greedy_generate(naive, prompt, 512)
+    g = gen.BucketedGreedyGenerator(hip, 1, 512, bucket=64, device=gpu_device)
+    first = g.generate(prompt)                       # captures the 8 graphs
+    again = g.generate(prompt)                       # pure replay
+    assert first == ref and again == ref
+    assert len(g._graphs) == 8
+    g3 = gen.BucketedGreedyGenerator(hip, 3, 160, bucket=32, device=gpu_device)
+    assert g3.generate([prompt] * 3) == [ref[0][:160]] * 3
+    # fused GELU (one HIP launch instead of eight torch ops, SURVEY 8(f) row 3) changes no token either
+    fused = gen.build_model("gpt2", Backend.CUSTOM_CUDA, gpu_device, seed=0, fused_gelu=True)
+    assert gen.greedy_generate(fused, prompt, 128) == [ref[0][:128]]
+    gf = gen.BucketedGreedyGenerator(fused, 1, 512, bucket=64, device=gpu_device)
+    assert gf.generate(prompt) == ref
