@@ -198,6 +198,26 @@ def main() -> None:
             others[name] = {"workload": o["desc"], "us_per_launch": round(us, 2), "tflops": round(tf, 2),
                             "frac_of_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
             del x, oo
+        # the fused tanh-GELU kernel: HBM-bound, 8 algorithmic bytes per element
+        for name, n in (("gelu_gpt2xl_b64_t512", 64 * 512 * 6400), ("gelu_gpt2_t256", 256 * 3072)):
+            gx = torch.randn(n, device=dev)
+            gy = torch.empty_like(gx)
+            ga = (gx.data_ptr(), gy.data_ptr(), n, ctypes.c_void_p(stream.cuda_stream))
+            for _ in range(3):
+                lib.gpt2_gelu_tanh_f32_fwd(*ga)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record(stream)
+            for _ in range(reps):
+                lib.gpt2_gelu_tanh_f32_fwd(*ga)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            gbs = lib.gpt2_gelu_algorithmic_bytes(n) / us / 1e3
+            others[name] = {"workload": f"fused tanh-GELU fp32, {n} elements", "us_per_launch": round(us, 2),
+                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                                         "frac": round(gbs / 8000.0, 4), "traffic": None}}
+            del gx, gy
     result = {
         "metric": "attention fp32 TFLOP/s (causal MHSA forward, F = 2*B*H*d*T*(T+1))",
         "value": round(value, 3),

@@ -1,8 +1,7 @@
 // gelu_fwd.hip -- fused tanh-GELU forward for MI355X (gfx950), C ABI in include/gpt2_gelu.h.
 //
-// HBM-bound elementwise kernel (8 algorithmic bytes per element, ~20 flops): one 16-B load and one 16-B
-// store per lane per step, four independent steps in flight per lane, grid sized to a few waves per SIMD and
-// grid-strided beyond that.  Arithmetic follows the reference expression tree (reference gelu.py:9-12) one
+// HBM-bound elementwise kernel (8 algorithmic bytes per element, ~20 flops + tanhf): 16-B loads and stores,
+// four independent loads in flight per lane, one 16-KiB contiguous chunk per workgroup.  Arithmetic follows the reference expression tree (reference gelu.py:9-12) one
 // rounded fp32 operation at a time -- __fmul_rn / __fadd_rn keep hipcc from contracting x + c*x^3 into an
 // FMA -- so the result matches PyTorch's eight-kernel evaluation of the same module bit for bit wherever
 // tanhf does.
@@ -15,10 +14,11 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr float kSqrt2OverPi = 0.7978845238685608f;   // sqrtf((float)(2/pi)) = torch.sqrt(torch.tensor(2.0 / torch.pi)), gelu.py:10
 constexpr float kCubic = 0.44715f;                    // gelu.py:11
 constexpr int kThreads = 256;
-constexpr int kUnroll = 4;
 
 __device__ __forceinline__ float gelu_one(float x) {
     const float x3 = __fmul_rn(__fmul_rn(x, x), x);                  // torch.pow(x, 3) == x*x*x
@@ -27,23 +27,28 @@ __device__ __forceinline__ float gelu_one(float x) {
     return __fmul_rn(__fmul_rn(0.5f, x), __fadd_rn(1.0f, t));
 }
 
-__global__ __launch_bounds__(kThreads) void gelu_vec_kernel(const float4 *x, float4 *y, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * kThreads;
-    int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    for (; i + (kUnroll - 1) * stride < n4; i += kUnroll * stride) {
-        float4 v[kUnroll];
+// One workgroup = one contiguous 16-KiB chunk (kUnroll x 256 float4): wave-instruction = 1 KiB contiguous, four
+// independent loads in flight per lane.  kStream: non-temporal loads/stores for arrays beyond the Infinity Cache
+// (every byte is touched once; measured 5.9 vs 4.4 TB/s on 839 MB); smaller activations -- just written by the
+// preceding GEMM, about to be read by the next -- stay on the cached path (3.7 vs 6.0 us on 3 MB).
+template <bool kStream, int kUnroll>
+__global__ __launch_bounds__(kThreads) void gelu_vec_kernel(const f32x4 *x, f32x4 *y, int64_t n4) {
+    const int64_t base = (int64_t)blockIdx.x * (kThreads * kUnroll) + threadIdx.x;
+    if (base - threadIdx.x + kThreads * kUnroll <= n4) {         // whole chunk inside (uniform): no per-load guards
+        f32x4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = x[i + u * stride];
+        for (int u = 0; u < kUnroll; ++u) v[u] = kStream ? __builtin_nontemporal_load(x + base + u * kThreads) : x[base + u * kThreads];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             v[u].x = gelu_one(v[u].x); v[u].y = gelu_one(v[u].y); v[u].z = gelu_one(v[u].z); v[u].w = gelu_one(v[u].w);
-            y[i + u * stride] = v[u];
+            if (kStream) __builtin_nontemporal_store(v[u], y + base + u * kThreads); else y[base + u * kThreads] = v[u];
         }
-    }
-    for (; i < n4; i += stride) {
-        float4 v = x[i];
-        v.x = gelu_one(v.x); v.y = gelu_one(v.y); v.z = gelu_one(v.z); v.w = gelu_one(v.w);
-        y[i] = v;
+    } else {
+        for (int64_t i = base; i < n4; i += kThreads) {
+            f32x4 v = x[i];
+            v.x = gelu_one(v.x); v.y = gelu_one(v.y); v.z = gelu_one(v.z); v.w = gelu_one(v.w);
+            y[i] = v;
+        }
     }
 }
 
@@ -73,9 +78,17 @@ int gpt2_gelu_tanh_f32_fwd(const float *x, float *y, int64_t n, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool aligned = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
     const int64_t n4 = aligned ? n / 4 : 0;
-    if (n4 > 0)
-        hipLaunchKernelGGL(gelu_vec_kernel, dim3(grid_for((n4 + kUnroll - 1) / kUnroll)), dim3(kThreads), 0, s,
-                           reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), n4);
+    const bool stream_past_caches = 8 * n > (128LL << 20);        // x + y larger than half the 256-MiB Infinity Cache
+    // small activations (generation: T x 4*d_model, a few MB) are latency-bound: one float4 per lane spreads them
+    // over every CU; large ones keep four loads in flight per lane
+    const int unroll = n4 >= (1 << 20) ? 4 : 1;
+    if (n4 > 0) {
+        void (*kernel)(const f32x4 *, f32x4 *, int64_t) = gelu_vec_kernel<false, 1>;
+        if (stream_past_caches) kernel = gelu_vec_kernel<true, 4>;
+        else if (unroll == 4) kernel = gelu_vec_kernel<false, 4>;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((n4 + kThreads * unroll - 1) / (kThreads * unroll))), dim3(kThreads), 0, s,
+                           reinterpret_cast<const f32x4 *>(x), reinterpret_cast<f32x4 *>(y), n4);
+    }
     const int64_t rest = n - 4 * n4;
     if (rest > 0)
         hipLaunchKernelGGL(gelu_scalar_kernel, dim3(grid_for(rest)), dim3(kThreads), 0, s, x + 4 * n4, y + 4 * n4, rest);
