@@ -183,7 +183,7 @@ class BucketedGreedyGenerator:
     and rows are trimmed after their first generated EOS, so the returned tokens equal greedy_generate()'s."""
 
     def __init__(self, model: "GPT2Model", batch: int, max_tokens: int, bucket: int = 64, eos_token: int = EOS_TOKEN,
-                 use_graphs: bool = True, check_every: int = 32, device=None):
+                 use_graphs: bool = True, check_every: int = 32, device=None, progress=None):
         self.model, self.batch, self.max_tokens, self.bucket, self.eos = model, batch, max_tokens, bucket, eos_token
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
         self.use_graphs = use_graphs
@@ -192,6 +192,7 @@ class BucketedGreedyGenerator:
         if max_tokens > model.cfg["context_length"]:
             raise ValueError("max_tokens exceeds the model's context length")
         self.check_every = check_every
+        self.progress = progress                                       # callable(length) at every EOS check, or None
         self.cap = -(-max_tokens // bucket) * bucket                  # buffer length: whole buckets
         self.cap = min(self.cap, model.cfg["context_length"])
         self.tokens = torch.zeros((batch, self.cap), dtype=torch.long, device=self.device)
@@ -255,8 +256,12 @@ class BucketedGreedyGenerator:
             else:
                 self._step(L)
             length += 1
-            if (length - plen) % self.check_every == 0 and bool(self.done.all()):
-                break                                                  # the reference stops at EOS (sampler.py:14)
+            if (length - plen) % self.check_every == 0:
+                all_done = bool(self.done.all())                       # the only host sync of the loop
+                if self.progress is not None:
+                    self.progress(length)
+                if all_done:
+                    break                                              # the reference stops at EOS (sampler.py:14)
         out = []
         for row in self.tokens[:, :length].tolist():
             cut = len(row)
@@ -318,6 +323,7 @@ def main() -> None:
     ap.add_argument("--threads", type=int, default=0, help="CPU threads for --device cpu (0 = all cores)")
     ap.add_argument("--graphs", action="store_true", help="bucketed static-buffer loop replayed as HIP graphs (one launch per token)")
     ap.add_argument("--bucket", type=int, default=64)
+    ap.add_argument("--progress", action="store_true", help="with --graphs: a line on stderr at every EOS check (32 tokens)")
     ap.add_argument("--fused-gelu", action="store_true", help="GELU as one HIP launch (include/gpt2_gelu.h) instead of eight torch ops")
     args = ap.parse_args()
 
@@ -345,7 +351,9 @@ def main() -> None:
     prompts = [list(REFERENCE_PROMPT_IDS) for _ in mine]
     if world > 1:
         dist.barrier()
-    gen = BucketedGreedyGenerator(model, len(prompts), args.max_tokens, bucket=args.bucket, device=device) if args.graphs and prompts else None
+    gen = BucketedGreedyGenerator(model, len(prompts), args.max_tokens, bucket=args.bucket, device=device,
+                                  progress=(lambda n: print(f"[rank {rank}] length {n}", file=sys.stderr, flush=True)) if args.progress else None) \
+        if args.graphs and prompts else None
     timing = time_greedy_generation(model, prompts, args.max_tokens, device, gen) if prompts else GenerationTiming(0, 0, 0, [])
     seconds = timing.second_run_seconds
     generated = sum(len(t) - len(REFERENCE_PROMPT_IDS) for t in timing.tokens)
