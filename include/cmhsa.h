@@ -70,6 +70,18 @@ int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,
                       int seq_len, int d_model, int num_heads,
                       void *stream);
 
+/* The same forward over ONE packed QKV buffer, as the model produces it: row t of batch b holds
+ * [ Q (d_model) | K (d_model) | V (d_model) ] -- the output of the fused QKV linear layer that the
+ * reference slices into three views before calling the op (reference causal_self_attention.py:224-227).
+ * Equivalent to cmhsa_fp32_fwd(qkv, qkv + d_model, qkv + 2*d_model, o, rs, rs, rs, o_row_stride, bs, bs,
+ * bs, o_batch_stride, ...) with d_model = num_heads * head_dim; one pointer and one stride pair to
+ * marshal instead of three.  Same status codes; a row stride below
+ * 3*d_model is CMHSA_ERR_BAD_SHAPE. */
+int cmhsa_fp32_fwd_packed_qkv(const float *qkv, float *o,
+                              int64_t qkv_row_stride, int64_t o_row_stride,
+                              int64_t qkv_batch_stride, int64_t o_batch_stride,
+                              int batch, int seq_len, int num_heads, int head_dim, void *stream);
+
 /* Algorithmic work of one call, the figure every TFLOP/s number in this repo uses
  * (SURVEY.md section 8(d)):  F = 2 * batch * num_heads * head_dim * T * (T+1). */
 double cmhsa_algorithmic_flops(int batch, int seq_len, int num_heads, int head_dim);

@@ -127,7 +127,8 @@ class CausalSelfAttention(nn.Module):
                  p_dropout: float,
                  num_heads: int,
                  qkv_bias: bool,
-                 scaled_dot_product_attention_backend: ScaledDotProductAttentionBackend):
+                 scaled_dot_product_attention_backend: ScaledDotProductAttentionBackend,
+                 packed_qkv: bool = False):
         super().__init__()
         if d_out % num_heads != 0:
             raise ValueError(f"d_out must be divisible by num_heads. d_out was {d_out} and num_heads was {num_heads}.")
@@ -136,6 +137,9 @@ class CausalSelfAttention(nn.Module):
         self.num_heads = num_heads
         self.head_dim = d_out // num_heads
         self.scaled_dot_product_attention_backend = scaled_dot_product_attention_backend
+        # opt-in, custom backend only: hand the QKV GEMM's output to the kernel as ONE buffer
+        # instead of three column views -- same kernel, same result bits, fewer host-side marshals per call
+        self.packed_qkv = packed_qkv and scaled_dot_product_attention_backend is ScaledDotProductAttentionBackend.CUSTOM_CUDA
         self.qkv_layer = nn.Linear(d_in, 3 * d_out, bias=qkv_bias)
         self.out_proj_layer = nn.Linear(d_out, d_out)
         self.dropout = nn.Dropout(p=p_dropout)      # defined but never applied, as in the reference (:216, :222-236)
@@ -143,6 +147,9 @@ class CausalSelfAttention(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         qkv = self.qkv_layer(x)
+        if self.packed_qkv:
+            return self.out_proj_layer(torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_packed_qkv(
+                QKV=qkv, num_heads=self.num_heads))
         # three column slices of ONE buffer: row stride 3*d_out, handed over as views (reference :225-227)
         q, k, v = (qkv[:, :, i * self.d_out:(i + 1) * self.d_out] for i in range(3))
         ctx = scaled_dot_product_attention(backend=self.scaled_dot_product_attention_backend,

@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "cmhsa_version",
     "cmhsa_fp32_fwd",
     "cmhsa_fp32_fwd_2d",
+    "cmhsa_fp32_fwd_packed_qkv",
     "cmhsa_algorithmic_flops",
     "gpt2_gelu_tanh_f32_fwd",        # include/gpt2_gelu.h
     "gpt2_gelu_algorithmic_bytes",
@@ -65,6 +66,8 @@ def load_library() -> ctypes.CDLL:
     lib.cmhsa_fp32_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp]
     lib.cmhsa_fp32_fwd_2d.restype = i32
     lib.cmhsa_fp32_fwd_2d.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp]
+    lib.cmhsa_fp32_fwd_packed_qkv.restype = i32
+    lib.cmhsa_fp32_fwd_packed_qkv.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, vp]
     lib.cmhsa_algorithmic_flops.restype = ctypes.c_double
     lib.cmhsa_algorithmic_flops.argtypes = [i32, i32, i32, i32]
     lib.gpt2_gelu_tanh_f32_fwd.restype = i32
@@ -129,6 +132,26 @@ def attention_fwd(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: 
         stream = torch.cuda.current_stream(Q.device).cuda_stream
         rc = attention_fwd_raw(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), rs, bs,
                                B, N, num_heads, d_model // num_heads, stream)
+    if rc != CMHSA_OK:
+        raise CmhsaError(rc, status_string(rc))
+    return out
+
+
+def attention_fwd_packed_qkv(QKV: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """cmhsa_fp32_fwd_packed_qkv: QKV is the (N, 3*d_model) or (B, N, 3*d_model) output of the fused QKV linear layer
+    (row = [Q | K | V], reference causal_self_attention.py:224-227); returns the (.., N, d_model) context."""
+    _check(QKV, "QKV")
+    if num_heads <= 0 or QKV.shape[-1] % (3 * num_heads) != 0:
+        raise ValueError("last dimension of QKV must be 3 * d_model with d_model divisible by the number of heads")
+    d_model = QKV.shape[-1] // 3
+    out = torch.empty(QKV.shape[:-1] + (d_model,), dtype=torch.float32, device=QKV.device)
+    batched = QKV.dim() == 3
+    with torch.cuda.device(QKV.device):
+        stream = torch.cuda.current_stream(QKV.device).cuda_stream
+        rc = load_library().cmhsa_fp32_fwd_packed_qkv(
+            QKV.data_ptr(), out.data_ptr(), QKV.stride(-2), out.stride(-2),
+            QKV.stride(0) if batched else 0, out.stride(0) if batched else 0,
+            QKV.shape[0] if batched else 1, QKV.shape[-2], num_heads, d_model // num_heads, ctypes.c_void_p(stream))
     if rc != CMHSA_OK:
         raise CmhsaError(rc, status_string(rc))
     return out

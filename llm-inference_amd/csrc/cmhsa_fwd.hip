@@ -613,4 +613,17 @@ int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,
                           1, seq_len, num_heads, d_model / num_heads, stream);
 }
 
+int cmhsa_fp32_fwd_packed_qkv(const float *qkv, float *o, int64_t qkv_row_stride, int64_t o_row_stride,
+                              int64_t qkv_batch_stride, int64_t o_batch_stride,
+                              int batch, int seq_len, int num_heads, int head_dim, void *stream) {
+    if (num_heads <= 0) return CMHSA_ERR_BAD_SHAPE;
+    if (head_dim != kHeadDim) return CMHSA_ERR_HEAD_DIM;
+    const int64_t d_model = (int64_t)num_heads * kHeadDim;
+    if (qkv_row_stride < 3 * d_model) return CMHSA_ERR_BAD_SHAPE;             // a row must hold Q | K | V
+    const float *k = qkv ? qkv + d_model : nullptr, *v = qkv ? qkv + 2 * d_model : nullptr;
+    return cmhsa_fp32_fwd(qkv, k, v, o, qkv_row_stride, qkv_row_stride, qkv_row_stride, o_row_stride,
+                          qkv_batch_stride, qkv_batch_stride, qkv_batch_stride, o_batch_stride,
+                          batch, seq_len, num_heads, head_dim, stream);
+}
+
 }  // extern "C"

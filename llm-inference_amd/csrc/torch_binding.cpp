@@ -22,6 +22,8 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <vector>
+
 #include "cmhsa.h"
 #include "gpt2_gelu.h"
 
@@ -71,6 +73,31 @@ at::Tensor causal_multihead_self_attention_torch(at::Tensor Q, at::Tensor K, at:
     return output;
 }
 
+// The same op over the packed output of the fused QKV linear layer (reference causal_self_attention.py:224-227
+// slices it into three views first): QKV is (N, 3*d_model) or (B, N, 3*d_model), row = [Q | K | V].
+// SURVEY.md 8(f) row 2; no reference schema to mirror -- the reference signature above stays the compatibility entry.
+at::Tensor causal_multihead_self_attention_packed_qkv(at::Tensor QKV, int64_t num_heads) {
+    const int64_t dim = QKV.dim();
+    TORCH_CHECK(dim == 2 || dim == 3, "QKV must be a 2D (N, 3*d_model) or 3D (B, N, 3*d_model) tensor");
+    check_one(QKV, "QKV", dim);
+    TORCH_CHECK(num_heads > 0 && QKV.size(dim - 1) % (3 * num_heads) == 0,
+                "last dimension of QKV must be 3 * d_model with d_model divisible by the number of heads");
+    const int64_t d = QKV.size(dim - 1) / 3, B = dim == 3 ? QKV.size(0) : 1, N = QKV.size(dim - 2);
+    TORCH_CHECK(d / num_heads == 64, "Head dimension must be 64.");
+    TORCH_CHECK(B <= INT32_MAX && N <= INT32_MAX && num_heads <= INT32_MAX, "shape exceeds 32-bit indexing");
+    std::vector<int64_t> out_sizes(QKV.sizes().begin(), QKV.sizes().end());
+    out_sizes.back() = d;
+    at::Tensor output = at::empty(out_sizes, QKV.options().memory_format(c10::MemoryFormat::Contiguous));
+    if (output.numel() == 0) return output;
+    const c10::hip::HIPGuard guard(QKV.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(QKV.device().index()).stream();
+    const int rc = cmhsa_fp32_fwd_packed_qkv(QKV.data_ptr<float>(), output.data_ptr<float>(), QKV.stride(dim - 2), output.stride(dim - 2),
+                                             dim == 3 ? QKV.stride(0) : 0, dim == 3 ? output.stride(0) : 0,
+                                             (int)B, (int)N, (int)num_heads, 64, stream);
+    TORCH_CHECK(rc == CMHSA_OK, "cmhsa_fp32_fwd_packed_qkv failed (", rc, "): ", cmhsa_status_string(rc));
+    return output;
+}
+
 // Fused tanh-GELU (reference gelu.py:4-12 is a plain nn.Module with no extension op, so
 // this op has no reference schema to mirror): any-shape contiguous fp32 device tensor in, new tensor out.
 at::Tensor gelu_tanh(at::Tensor x) {
@@ -88,11 +115,13 @@ at::Tensor gelu_tanh(at::Tensor x) {
 
 TORCH_LIBRARY(causal_multihead_self_attention, m) {
     m.def("causal_multihead_self_attention_torch(Tensor Q, Tensor K, Tensor V, int num_heads) -> Tensor");
+    m.def("causal_multihead_self_attention_packed_qkv(Tensor QKV, int num_heads) -> Tensor");
     m.def("gelu_tanh(Tensor x) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
     m.impl("causal_multihead_self_attention_torch", &causal_multihead_self_attention_torch);
+    m.impl("causal_multihead_self_attention_packed_qkv", &causal_multihead_self_attention_packed_qkv);
     m.impl("gelu_tanh", &gelu_tanh);
 }
 

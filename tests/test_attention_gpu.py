@@ -224,3 +224,37 @@ def test_full_size_properties_config5_shape(gpu_device):
         want = oracle.naive_attention_f64(Q[b, :, sl].cpu().numpy(), K[b, :, sl].cpu().numpy(),
                                           V1[b, :, sl].cpu().numpy(), 1)
         assert np.abs(o1[b, :, sl].cpu().numpy() - want).max() <= TOL
+
+
+@pytest.mark.gpu
+def test_packed_qkv_entry_point_equals_the_three_view_call(gpu_device):
+    """one packed (.., T, 3*d_model) buffer in -- same kernel, so the same bits as slicing it into
+    the three views the reference hands over (causal_self_attention.py:224-227); C ABI, torch op and module flag."""
+    import causal_multihead_self_attention  # noqa: F401
+    from causal_self_attention import CausalSelfAttention, ScaledDotProductAttentionBackend as Backend
+
+    torch.manual_seed(21)
+    for B, T, H in ((1, 1, 12), (1, 199, 12), (1, 1024, 12), (3, 130, 25), (2, 64, 16)):
+        d = 64 * H
+        qkv = torch.randn(B, T, 3 * d, device=gpu_device)
+        want = cmhsa.attention_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H)
+        assert torch.equal(cmhsa.attention_fwd_packed_qkv(qkv, H), want)
+        op = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_packed_qkv
+        assert torch.equal(op(QKV=qkv, num_heads=H), want)
+        if B == 1:
+            assert torch.equal(op(QKV=qkv[0], num_heads=H), want[0])
+    # padded rows (row stride > 3*d_model) are fine, too-narrow / mis-shaped inputs raise
+    wide = torch.randn(50, 3 * 768 + 64, device=gpu_device)
+    got = cmhsa.attention_fwd_packed_qkv(wide[:, :3 * 768], 12)
+    assert torch.equal(got, cmhsa.attention_fwd(wide[:, :768], wide[:, 768:1536], wide[:, 1536:2304], 12))
+    with pytest.raises(RuntimeError):
+        op(QKV=torch.randn(8, 3 * 768 + 4, device=gpu_device), num_heads=12)
+    with pytest.raises(RuntimeError):
+        op(QKV=torch.randn(8, 3 * 96, device=gpu_device), num_heads=3)           # head_dim 32
+    torch.manual_seed(22)
+    a = CausalSelfAttention(768, 768, 256, 0.1, 12, True, Backend.CUSTOM_CUDA).to(gpu_device).eval()
+    b = CausalSelfAttention(768, 768, 256, 0.1, 12, True, Backend.CUSTOM_CUDA, packed_qkv=True).to(gpu_device).eval()
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, 200, 768, device=gpu_device)
+    with torch.no_grad():
+        assert torch.equal(a(x), b(x))
