@@ -50,7 +50,6 @@ constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
 constexpr int kWaveLdsFloats = 2 * kUnitFloats;           // K + V = 16 KiB per wave
 constexpr int lds_bytes(int waves) { return (waves * kWaveLdsFloats + 2 * kUnitFloats) * 4; }   // + two shared, pre-scaled Q blocks
-constexpr int kCombStride = 33;                           // O^T merge image: [64 d][32 q + 1 pad]
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
 constexpr float kRescaleThreshold = 16.f;                 // lazy rescale: keep the old max while it is within 2^16
 
@@ -80,7 +79,6 @@ struct Params {
     int64_t q_bs, k_bs, v_bs, o_bs;     // batch strides (floats)
     int seq_len;                        // N
     int num_heads;                      // H
-    int bh;                             // batch * H
     int nqb;                            // ceil(N / 32)
     int grid_x;                         // gridDim.x: 8 when (b,h)s are pinned to XCDs, else bh (see the kernel)
     unsigned heads_magic, chain_magic;  // floor((2^32-1) / num_heads), floor((2^32-1) / chain): udiv_magic()
@@ -88,7 +86,6 @@ struct Params {
     int chain;                          // c: max units any wave processes = ceil(nqb / kWaves)
     int n_paired;                       // R: query blocks 1..R units long are paired n <-> R+1-n
     int n_alone;                        // nqb - R: the longest query blocks get a workgroup each
-    int wgs_per_bh;                     // n_alone + ceil(R / 2)
 };
 
 // Packing plan.  A query block with n units gets g(n) = ceil(n / c) waves, so that no wave runs more than
@@ -592,12 +589,11 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     p.q_bs = q_batch_stride; p.k_bs = k_batch_stride; p.v_bs = v_batch_stride; p.o_bs = o_batch_stride;
     p.seq_len = seq_len;
     p.num_heads = num_heads;
-    p.bh = (int)bh;
     p.nqb = (int)nqb;
     p.grid_x = (int)grid.x;
     p.heads_magic = 0xffffffffu / (unsigned)num_heads;
     p.chain_magic = 0xffffffffu / (unsigned)pl.chain;
-    p.chain = pl.chain; p.n_paired = pl.n_paired; p.n_alone = pl.n_alone; p.wgs_per_bh = pl.wgs_per_bh;
+    p.chain = pl.chain; p.n_paired = pl.n_paired; p.n_alone = pl.n_alone;
 
     hipError_t e = waves == 8 ? launch<8>(p, grid, stream) : launch<4>(p, grid, stream);
     if (e != hipSuccess) return (int)e;

@@ -258,3 +258,30 @@ def test_packed_qkv_entry_point_equals_the_three_view_call(gpu_device):
     x = torch.randn(2, 200, 768, device=gpu_device)
     with torch.no_grad():
         assert torch.equal(a(x), b(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,H", [(16384, 1), (12345, 3), (33000, 1)])
+def test_long_sequences_spot_rows_against_f64(gpu_device, T, H):
+    """Long, ragged sequences (hundreds to a thousand query blocks: every branch of the packing plan, both workgroup
+    shapes): spot rows against an fp64 evaluation of the reference formula on the GPU's inputs, first row = V[0],
+    constant-V invariance, full write of the output."""
+    torch.manual_seed(31)
+    d = 64 * H
+    qkv = torch.randn(T, 3 * d, device=gpu_device)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    out = torch.full((T, d), float("nan"), device=gpu_device)
+    cmhsa.attention_fwd(q, k, v, H, out=out)
+    assert not torch.isnan(out).any()
+    assert torch.allclose(out[0], v[0], atol=1e-6)
+    rows = [1, 31, 32, 33, 1023, 1024, T // 2, T - 33, T - 32, T - 1]
+    q64, k64, v64 = q.double(), k.double(), v.double()
+    for h in range(H):
+        sl = slice(64 * h, 64 * h + 64)
+        for r in rows:
+            w = torch.softmax((k64[:r + 1, sl] @ q64[r, sl]) / 8.0, dim=0)
+            want = w @ v64[:r + 1, sl]
+            assert (out[r, sl].double() - want).abs().max().item() <= 1e-4
+    ones = torch.full_like(v, 0.75)
+    const = cmhsa.attention_fwd(q, k, ones, H)
+    assert (const - 0.75).abs().max().item() <= 5e-6 * 64
