@@ -82,6 +82,30 @@ int cmhsa_fp32_fwd_packed_qkv(const float *qkv, float *o,
                               int64_t qkv_batch_stride, int64_t o_batch_stride,
                               int batch, int seq_len, int num_heads, int head_dim, void *stream);
 
+/* One-token ("decode") step over a KV cache -- opt-in, SURVEY.md section 8(f) row 4.  The reference keeps no
+ * KV cache (README.md:12-13; sampler.py:14-19 re-runs the full forward per token); this entry point computes
+ * only the LAST row of the same formula (causal_self_attention.py:173-194) for a token whose q, k, v have just
+ * come out of the fused QKV layer, and appends that k, v to the cache in the same launch.  Per (b, h):
+ *     k_cache[b, pos, 64h:64h+64] = k_new ;  v_cache[b, pos, ...] = v_new
+ *     o[b, 64h:64h+64] = softmax( q_new . K[b, 0..pos]^T / 8 ) V[b, 0..pos]
+ *   qkv_new   : (batch, 3*d_model), row b = [ q | k | v ] of the new token (row stride >= 3*d_model)
+ *   k_cache,
+ *   v_cache   : (batch, capacity, d_model), element (b, t, c) at ptr[b*cache_batch_stride + t*cache_row_stride + c];
+ *               rows 0..pos-1 hold the earlier tokens (e.g. written by a prefill through cmhsa_fp32_fwd)
+ *   o         : (batch, d_model), row stride o_row_stride
+ *   pos_dev   : DEVICE pointer to one int32 = index of the new token, 0 <= pos < capacity.  It is read by the
+ *               kernel, not by the host, so a captured HIP graph of the step can be replayed for every token; a
+ *               value outside [0, capacity) makes the launch a no-op (nothing read, nothing written).
+ * HBM/L2-bound; no allocation, no synchronisation; same status codes as cmhsa_fp32_fwd. */
+int cmhsa_fp32_decode_step(const float *qkv_new, int64_t qkv_row_stride,
+                           float *k_cache, float *v_cache, int64_t cache_row_stride, int64_t cache_batch_stride,
+                           float *o, int64_t o_row_stride, const int *pos_dev,
+                           int batch, int capacity, int num_heads, int head_dim, void *stream);
+
+/* Algorithmic HBM bytes of one decode step with num_keys = pos + 1 keys:
+ * 4 * batch * d_model * (2*num_keys + 6)  (every K and V row once, q/k/v in, the appended rows and o out). */
+double cmhsa_decode_algorithmic_bytes(int batch, int num_keys, int num_heads, int head_dim);
+
 /* Algorithmic work of one call, the figure every TFLOP/s number in this repo uses
  * (SURVEY.md section 8(d)):  F = 2 * batch * num_heads * head_dim * T * (T+1). */
 double cmhsa_algorithmic_flops(int batch, int seq_len, int num_heads, int head_dim);

@@ -44,7 +44,7 @@ def _run(cmd: list[str]) -> None:
 
 
 def build_kernel_lib(force: bool = False) -> str:
-    hip = [os.path.join(CSRC, "cmhsa_fwd.hip"), os.path.join(CSRC, "gelu_fwd.hip")]
+    hip = [os.path.join(CSRC, "cmhsa_fwd.hip"), os.path.join(CSRC, "cmhsa_decode.hip"), os.path.join(CSRC, "gelu_fwd.hip")]
     headers = [os.path.join(INCLUDE, "cmhsa.h"), os.path.join(INCLUDE, "gpt2_gelu.h")]
     if force or _stale(KERNEL_LIB, hip + headers):
         os.makedirs(LIBDIR, exist_ok=True)

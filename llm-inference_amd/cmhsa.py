@@ -26,6 +26,8 @@ EXPORTED_SYMBOLS = (
     "cmhsa_fp32_fwd",
     "cmhsa_fp32_fwd_2d",
     "cmhsa_fp32_fwd_packed_qkv",
+    "cmhsa_fp32_decode_step",
+    "cmhsa_decode_algorithmic_bytes",
     "cmhsa_algorithmic_flops",
     "gpt2_gelu_tanh_f32_fwd",        # include/gpt2_gelu.h
     "gpt2_gelu_algorithmic_bytes",
@@ -68,6 +70,10 @@ def load_library() -> ctypes.CDLL:
     lib.cmhsa_fp32_fwd_2d.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp]
     lib.cmhsa_fp32_fwd_packed_qkv.restype = i32
     lib.cmhsa_fp32_fwd_packed_qkv.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, vp]
+    lib.cmhsa_fp32_decode_step.restype = i32
+    lib.cmhsa_fp32_decode_step.argtypes = [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, vp]
+    lib.cmhsa_decode_algorithmic_bytes.restype = ctypes.c_double
+    lib.cmhsa_decode_algorithmic_bytes.argtypes = [i32, i32, i32, i32]
     lib.cmhsa_algorithmic_flops.restype = ctypes.c_double
     lib.cmhsa_algorithmic_flops.argtypes = [i32, i32, i32, i32]
     lib.gpt2_gelu_tanh_f32_fwd.restype = i32
@@ -152,6 +158,33 @@ def attention_fwd_packed_qkv(QKV: torch.Tensor, num_heads: int) -> torch.Tensor:
             QKV.data_ptr(), out.data_ptr(), QKV.stride(-2), out.stride(-2),
             QKV.stride(0) if batched else 0, out.stride(0) if batched else 0,
             QKV.shape[0] if batched else 1, QKV.shape[-2], num_heads, d_model // num_heads, ctypes.c_void_p(stream))
+    if rc != CMHSA_OK:
+        raise CmhsaError(rc, status_string(rc))
+    return out
+
+
+def decode_step(qkv_new: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, pos: torch.Tensor, num_heads: int,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    """cmhsa_fp32_decode_step (opt-in KV-cache mode): qkv_new (B, 3*d_model) of the new token, caches (B, capacity,
+    d_model) updated in place at row `pos` (int32 device tensor, one element); returns the (B, d_model) context."""
+    for t in (qkv_new, k_cache, v_cache):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1:
+            raise ValueError("qkv_new, k_cache and v_cache must be float32 CUDA tensors with last-dim stride 1")
+    if not pos.is_cuda or pos.dtype != torch.int32 or pos.numel() != 1:
+        raise ValueError("pos must be an int32 CUDA tensor with one element")
+    if qkv_new.dim() != 2 or k_cache.dim() != 3 or k_cache.shape != v_cache.shape or k_cache.stride() != v_cache.stride():
+        raise ValueError("qkv_new must be (B, 3*d_model); k_cache and v_cache (B, capacity, d_model) with equal strides")
+    B, d_model = qkv_new.shape[0], qkv_new.shape[1] // 3
+    if num_heads <= 0 or qkv_new.shape[1] != 3 * d_model or d_model % num_heads or k_cache.shape[0] != B or k_cache.shape[2] != d_model:
+        raise ValueError("shape mismatch between qkv_new, the caches and num_heads")
+    if out is None:
+        out = torch.empty((B, d_model), dtype=torch.float32, device=qkv_new.device)
+    with torch.cuda.device(qkv_new.device):
+        stream = torch.cuda.current_stream(qkv_new.device).cuda_stream
+        rc = load_library().cmhsa_fp32_decode_step(
+            qkv_new.data_ptr(), qkv_new.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), k_cache.stride(1), k_cache.stride(0),
+            out.data_ptr(), out.stride(0), pos.data_ptr(), B, k_cache.shape[1], num_heads, d_model // num_heads,
+            ctypes.c_void_p(stream))
     if rc != CMHSA_OK:
         raise CmhsaError(rc, status_string(rc))
     return out

@@ -98,6 +98,34 @@ at::Tensor causal_multihead_self_attention_packed_qkv(at::Tensor QKV, int64_t nu
     return output;
 }
 
+// One-token decode step over a KV cache (opt-in; the reference has no KV cache, so there is no
+// reference schema): appends the new token's k, v to the caches at row `pos` and returns its context row.
+//   qkv_new (B, 3*d_model) | k_cache, v_cache (B, capacity, d_model), updated in place | pos: int32 device tensor, 1 element
+at::Tensor causal_multihead_self_attention_decode(at::Tensor qkv_new, at::Tensor k_cache, at::Tensor v_cache, at::Tensor pos,
+                                                  int64_t num_heads) {
+    for (const at::Tensor *t : {&qkv_new, &k_cache, &v_cache}) {
+        TORCH_CHECK(t->is_cuda() && t->dtype() == at::kFloat, "qkv_new, k_cache and v_cache must be float32 CUDA tensors");
+        TORCH_CHECK(t->stride(t->dim() - 1) == 1, "last-dim stride must be 1");
+    }
+    TORCH_CHECK(pos.is_cuda() && pos.dtype() == at::kInt && pos.numel() == 1, "pos must be an int32 CUDA tensor with one element");
+    TORCH_CHECK(qkv_new.dim() == 2 && k_cache.dim() == 3 && v_cache.dim() == 3, "qkv_new must be (B, 3*d_model), caches (B, capacity, d_model)");
+    TORCH_CHECK(num_heads > 0 && qkv_new.size(1) % (3 * num_heads) == 0, "last dimension of qkv_new must be 3 * d_model");
+    const int64_t B = qkv_new.size(0), d = qkv_new.size(1) / 3, cap = k_cache.size(1);
+    TORCH_CHECK(d / num_heads == 64, "Head dimension must be 64.");
+    TORCH_CHECK(k_cache.sizes() == v_cache.sizes() && k_cache.strides() == v_cache.strides(), "k_cache and v_cache must have the same shape and strides");
+    TORCH_CHECK(k_cache.size(0) == B && k_cache.size(2) == d, "cache shape must be (B, capacity, d_model)");
+    TORCH_CHECK(B <= INT32_MAX && cap <= INT32_MAX, "shape exceeds 32-bit indexing");
+    at::Tensor output = at::empty({B, d}, qkv_new.options());
+    if (output.numel() == 0) return output;
+    const c10::hip::HIPGuard guard(qkv_new.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(qkv_new.device().index()).stream();
+    const int rc = cmhsa_fp32_decode_step(qkv_new.data_ptr<float>(), qkv_new.stride(0), k_cache.data_ptr<float>(), v_cache.data_ptr<float>(),
+                                          k_cache.stride(1), k_cache.stride(0), output.data_ptr<float>(), output.stride(0),
+                                          pos.data_ptr<int>(), (int)B, (int)cap, (int)num_heads, 64, stream);
+    TORCH_CHECK(rc == CMHSA_OK, "cmhsa_fp32_decode_step failed (", rc, "): ", cmhsa_status_string(rc));
+    return output;
+}
+
 // Fused tanh-GELU (reference gelu.py:4-12 is a plain nn.Module with no extension op, so
 // this op has no reference schema to mirror): any-shape contiguous fp32 device tensor in, new tensor out.
 at::Tensor gelu_tanh(at::Tensor x) {
@@ -116,12 +144,14 @@ at::Tensor gelu_tanh(at::Tensor x) {
 TORCH_LIBRARY(causal_multihead_self_attention, m) {
     m.def("causal_multihead_self_attention_torch(Tensor Q, Tensor K, Tensor V, int num_heads) -> Tensor");
     m.def("causal_multihead_self_attention_packed_qkv(Tensor QKV, int num_heads) -> Tensor");
+    m.def("causal_multihead_self_attention_decode(Tensor qkv_new, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor pos, int num_heads) -> Tensor");
     m.def("gelu_tanh(Tensor x) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
     m.impl("causal_multihead_self_attention_torch", &causal_multihead_self_attention_torch);
     m.impl("causal_multihead_self_attention_packed_qkv", &causal_multihead_self_attention_packed_qkv);
+    m.impl("causal_multihead_self_attention_decode", &causal_multihead_self_attention_decode);
     m.impl("gelu_tanh", &gelu_tanh);
 }
 

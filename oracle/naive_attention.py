@@ -132,3 +132,19 @@ def naive_attention_c(queries: np.ndarray, keys: np.ndarray, values: np.ndarray,
     if rc != 0:
         raise RuntimeError(f"oracle_naive_attention_f32 failed: {rc}")
     return out[0] if squeeze else out
+
+
+def decode_step_f64(q, K, V, num_heads: int, head_dim: int = 64):
+    """Last row of the reference formula (causal_self_attention.py:173-194) for ONE new token: q (d_model,), K and V
+    (n, d_model) = every key/value up to and including the new token's own.  float64 numpy.  What a KV-cache decode
+    step must return; the reference itself never computes a single row."""
+    import numpy as np
+
+    q = np.asarray(q, dtype=np.float64); K = np.asarray(K, dtype=np.float64); V = np.asarray(V, dtype=np.float64)
+    out = np.empty(num_heads * head_dim)
+    for h in range(num_heads):
+        sl = slice(h * head_dim, (h + 1) * head_dim)
+        s = K[:, sl] @ q[sl] / np.sqrt(head_dim)
+        w = np.exp(s - s.max()); w /= w.sum()
+        out[sl] = w @ V[:, sl]
+    return out
