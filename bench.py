@@ -218,6 +218,31 @@ def main() -> None:
                             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                          "frac": round(gbs / 8000.0, 4), "traffic": None}}
             del gx, gy
+        # the KV-cache decode step (opt-in): HBM/L2-bound, reads every cached K and V row once
+        for name, (db, dh, keys) in (("decode_b64_h25_k512", (64, 25, 512)), ("decode_b1_h12_k512", (1, 12, 512))):
+            dd = 64 * dh
+            kc = torch.randn((db, keys, dd), device=dev)
+            vc = torch.randn((db, keys, dd), device=dev)
+            new = torch.randn((db, 3 * dd), device=dev)
+            do = torch.empty((db, dd), device=dev)
+            pos = torch.tensor([keys - 1], dtype=torch.int32, device=dev)
+            da = (new.data_ptr(), new.stride(0), kc.data_ptr(), vc.data_ptr(), kc.stride(1), kc.stride(0), do.data_ptr(), do.stride(0),
+                  pos.data_ptr(), db, keys, dh, 64, ctypes.c_void_p(stream.cuda_stream))
+            for _ in range(3):
+                lib.cmhsa_fp32_decode_step(*da)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50
+            e0.record(stream)
+            for _ in range(reps):
+                lib.cmhsa_fp32_decode_step(*da)
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            gbs = lib.cmhsa_decode_algorithmic_bytes(db, keys, dh, 64) / us / 1e3
+            others[name] = {"workload": f"KV-cache decode step fp32, B={db} H={dh}, {keys} keys", "us_per_launch": round(us, 2),
+                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                                         "frac": round(gbs / 8000.0, 4), "traffic": None}}
+            del kc, vc
     result = {
         "metric": "attention fp32 TFLOP/s (causal MHSA forward, F = 2*B*H*d*T*(T+1))",
         "value": round(value, 3),

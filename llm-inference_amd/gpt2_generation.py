@@ -273,6 +273,139 @@ class BucketedGreedyGenerator:
         return out
 
 
+class KVCacheGreedyGenerator:
+    """Greedy decoding WITH a KV cache -- opt-in, SURVEY.md section 8(f) row 4.  The reference deliberately has none
+    (README.md:12-13): its loop recomputes every earlier position for every token.  Here each layer keeps the keys and
+    values of the earlier tokens in a static (B, max_tokens, d_model) pair; the prompt (all but its last token) is
+    run once through the ordinary full-sequence path to fill them, and every further token costs ONE position:
+
+        token[pos] -> embeddings -> per layer: LN, QKV GEMM (1 row), cmhsa_fp32_decode_step (appends k, v at row pos and
+        returns softmax(q.K[0..pos]^T/8) V[0..pos]), out-proj, MLP -> final LN -> LM head -> argmax -> token[pos+1]
+
+    `pos` lives in device memory and the kernel reads it there, so the step has a fixed shape and is captured as ONE
+    HIP graph that is replayed for every token (use_graphs=True).  Mathematically the logits are those of the
+    reference loop; numerically the GEMMs see one row instead of T, so the last bits differ and token identity with
+    the cache-less loop is an empirical property of the margins (tests/test_generation.py checks it on the GPU).
+
+    `decode_fn(qkv_new, k_cache, v_cache, pos_i32, num_heads) -> (B, d_model)` defaults to the HIP op; CPU tests inject
+    a torch restatement (there is no CPU fallback in the product path)."""
+
+    def __init__(self, model: "GPT2Model", batch: int, max_tokens: int, eos_token: int = EOS_TOKEN, use_graphs: bool = True,
+                 check_every: int = 32, device=None, decode_fn=None, progress=None):
+        self.model, self.batch, self.max_tokens, self.eos = model, batch, max_tokens, eos_token
+        self.device = torch.device(device) if device is not None else next(model.parameters()).device
+        if use_graphs and self.device.type != "cuda":
+            raise RuntimeError("HIP graphs need a GPU; pass use_graphs=False for the eager form of the same step")
+        if max_tokens > model.cfg["context_length"]:
+            raise ValueError("max_tokens exceeds the model's context length")
+        if decode_fn is None:
+            import causal_multihead_self_attention  # noqa: F401  (registers the op; ImportError = no silent fallback)
+
+            decode_fn = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_decode
+        self.decode_fn, self.use_graphs, self.check_every, self.progress = decode_fn, use_graphs, check_every, progress
+        d = model.cfg["emb_dim"]
+        dev = self.device
+        self.k_cache = [torch.zeros((batch, max_tokens, d), device=dev) for _ in model.blocks]
+        self.v_cache = [torch.zeros((batch, max_tokens, d), device=dev) for _ in model.blocks]
+        self.tokens = torch.zeros((batch, max_tokens + 1), dtype=torch.long, device=dev)    # +1: the last step's write slot
+        self.pos64 = torch.zeros((1,), dtype=torch.long, device=dev)       # index of the token the step consumes
+        self.pos32 = torch.zeros((1,), dtype=torch.int32, device=dev)      # the same, as the kernel wants it
+        self.done = torch.zeros((batch,), dtype=torch.bool, device=dev)
+        self._graph = None
+
+    @torch.no_grad()
+    def _prefill(self, n: int) -> None:
+        """Run tokens[:, :n] through the blocks with the model's own full-sequence attention; keep every layer's K, V."""
+        from causal_self_attention import scaled_dot_product_attention
+
+        m = self.model
+        x = m.token_embeddings(self.tokens[:, :n]) + m.positional_embeddings(torch.arange(n, device=self.device))
+        for i, blk in enumerate(m.blocks):
+            a = blk.attention
+            qkv = a.qkv_layer(blk.first_layer_norm(x))
+            q, k, v = (qkv[:, :, j * a.d_out:(j + 1) * a.d_out] for j in range(3))
+            self.k_cache[i][:, :n] = k
+            self.v_cache[i][:, :n] = v
+            ctx = scaled_dot_product_attention(backend=a.scaled_dot_product_attention_backend, queries=q, keys=k, values=v,
+                                               num_heads=a.num_heads, causal_mask=a.causal_mask)
+            x = x + a.out_proj_layer(ctx)
+            x = x + blk.mlp_out(blk.gelu(blk.mlp_in(blk.second_layer_norm(x))))
+
+    @torch.no_grad()
+    def _step(self) -> None:
+        m = self.model
+        tok = self.tokens.index_select(1, self.pos64)                                  # (B, 1)
+        x = m.token_embeddings(tok) + m.positional_embeddings(self.pos64)              # (B, 1, d)
+        for i, blk in enumerate(m.blocks):
+            a = blk.attention
+            qkv = a.qkv_layer(blk.first_layer_norm(x))                                 # (B, 1, 3d)
+            ctx = self.decode_fn(qkv[:, 0, :], self.k_cache[i], self.v_cache[i], self.pos32, a.num_heads)
+            x = x + a.out_proj_layer(ctx).unsqueeze(1)
+            x = x + blk.mlp_out(blk.gelu(blk.mlp_in(blk.second_layer_norm(x))))
+        nxt = torch.argmax(m.output_layer(m.layer_norm(x))[:, 0, :], dim=-1)
+        nxt = torch.where(self.done, torch.full_like(nxt, self.eos), nxt)
+        self.done.logical_or_(nxt == self.eos)
+        self.pos64.add_(1)
+        self.pos32.add_(1)
+        self.tokens.index_copy_(1, self.pos64, nxt.unsqueeze(1))
+
+    def _capture(self) -> None:
+        saved = [t.clone() for t in (self.tokens, self.pos64, self.pos32, self.done)]
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._step()                                   # warm-up: lazy initialisations must not land in the capture
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._step()
+        for dst, src in zip((self.tokens, self.pos64, self.pos32, self.done), saved):
+            dst.copy_(src)                                 # undo the warm-up step (its cache row is rewritten by the real one)
+
+    @torch.no_grad()
+    def generate(self, prompt_ids) -> list[list[int]]:
+        prompt = torch.as_tensor(prompt_ids, dtype=torch.long, device=self.device)
+        if prompt.dim() == 1:
+            prompt = prompt.unsqueeze(0)
+        if prompt.shape[0] != self.batch:
+            raise ValueError(f"generator was built for batch {self.batch}, got {prompt.shape[0]} prompts")
+        plen = prompt.shape[1]
+        if plen < 1 or plen > self.max_tokens:
+            raise ValueError("prompt length must be in [1, max_tokens]")
+        self.tokens.zero_()
+        self.tokens[:, :plen] = prompt
+        self.done.zero_()
+        length = plen
+        if length < self.max_tokens:
+            if plen > 1:
+                self._prefill(plen - 1)                    # the last prompt token is the first decode step's input
+            self.pos64.fill_(plen - 1)
+            self.pos32.fill_(plen - 1)
+            if self.use_graphs and self._graph is None:
+                self._capture()
+        while length < self.max_tokens:
+            if self.use_graphs:
+                self._graph.replay()
+            else:
+                self._step()
+            length += 1
+            if (length - plen) % self.check_every == 0:
+                all_done = bool(self.done.all())           # the only host sync of the loop
+                if self.progress is not None:
+                    self.progress(length)
+                if all_done:
+                    break                                  # the reference stops at EOS (sampler.py:14)
+        out = []
+        for row in self.tokens[:, :length].tolist():
+            cut = len(row)
+            for i in range(plen, len(row)):
+                if row[i] == self.eos:
+                    cut = i + 1
+                    break
+            out.append(row[:cut])
+        return out
+
+
 @dataclass
 class GenerationTiming:
     first_run_seconds: float
@@ -281,7 +414,7 @@ class GenerationTiming:
     tokens: list
 
 
-def time_greedy_generation(model, prompt_ids, max_tokens: int, device, generator: "BucketedGreedyGenerator | None" = None) -> GenerationTiming:
+def time_greedy_generation(model, prompt_ids, max_tokens: int, device, generator=None) -> GenerationTiming:
     """Mirror of reference gpt2.py:104-134: warm-up run of prompt+3 tokens, then the timed run.  With a
     BucketedGreedyGenerator the warm-up is one full generation instead (it captures the graphs, the analogue of the
     reference's warm-up paying for lazy initialisation), and the timed run replays them."""
@@ -323,6 +456,7 @@ def main() -> None:
     ap.add_argument("--threads", type=int, default=0, help="CPU threads for --device cpu (0 = all cores)")
     ap.add_argument("--graphs", action="store_true", help="bucketed static-buffer loop replayed as HIP graphs (one launch per token)")
     ap.add_argument("--bucket", type=int, default=64)
+    ap.add_argument("--kv-cache", action="store_true", help="opt-in KV-cache decoding (one position per token, one HIP graph); not the reference's algorithm")
     ap.add_argument("--progress", action="store_true", help="with --graphs: a line on stderr at every EOS check (32 tokens)")
     ap.add_argument("--fused-gelu", action="store_true", help="GELU as one HIP launch (include/gpt2_gelu.h) instead of eight torch ops")
     args = ap.parse_args()
@@ -351,9 +485,12 @@ def main() -> None:
     prompts = [list(REFERENCE_PROMPT_IDS) for _ in mine]
     if world > 1:
         dist.barrier()
-    gen = BucketedGreedyGenerator(model, len(prompts), args.max_tokens, bucket=args.bucket, device=device,
-                                  progress=(lambda n: print(f"[rank {rank}] length {n}", file=sys.stderr, flush=True)) if args.progress else None) \
-        if args.graphs and prompts else None
+    progress = (lambda n: print(f"[rank {rank}] length {n}", file=sys.stderr, flush=True)) if args.progress else None
+    gen = None
+    if prompts and args.kv_cache:
+        gen = KVCacheGreedyGenerator(model, len(prompts), args.max_tokens, device=device, progress=progress)
+    elif prompts and args.graphs:
+        gen = BucketedGreedyGenerator(model, len(prompts), args.max_tokens, bucket=args.bucket, device=device, progress=progress)
     timing = time_greedy_generation(model, prompts, args.max_tokens, device, gen) if prompts else GenerationTiming(0, 0, 0, [])
     seconds = timing.second_run_seconds
     generated = sum(len(t) - len(REFERENCE_PROMPT_IDS) for t in timing.tokens)
@@ -371,7 +508,7 @@ def main() -> None:
         tokens = timing.tokens
     if rank == 0:
         print(json.dumps({
-            "model": args.model, "backend": args.backend, "loop": f"hip graphs, bucket {args.bucket}" if args.graphs else "eager (reference loop)", "gelu": "fused HIP kernel" if args.fused_gelu else "reference expression (8 torch ops)", "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
+            "model": args.model, "backend": args.backend, "loop": "kv cache, one hip graph" if args.kv_cache else f"hip graphs, bucket {args.bucket}" if args.graphs else "eager (reference loop)", "gelu": "fused HIP kernel" if args.fused_gelu else "reference expression (8 torch ops)", "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
             "cpu_threads": torch.get_num_threads() if device.type == "cpu" else None,
             "weights": args.weights or "random (torch.manual_seed(0))", "prompts": args.batch, "max_tokens": args.max_tokens,
             "warmup_seconds": round(timing.first_run_seconds, 4), "seconds": round(seconds, 4),

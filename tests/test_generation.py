@@ -125,6 +125,31 @@ def test_bucketed_loop_eos_semantics():
         gen.BucketedGreedyGenerator(m2, 1, 6, use_graphs=True, device="cpu")
 
 
+def _torch_decode(qkv_new, k_cache, v_cache, pos, num_heads):
+    """Torch restatement of cmhsa_fp32_decode_step for the CPU tests (append k, v at row pos; last attention row)."""
+    B, d = qkv_new.shape[0], qkv_new.shape[1] // 3
+    p = int(pos.item())
+    k_cache[:, p] = qkv_new[:, d:2 * d]
+    v_cache[:, p] = qkv_new[:, 2 * d:]
+    q = qkv_new[:, :d].view(B, num_heads, 1, 64)
+    k = k_cache[:, :p + 1].view(B, p + 1, num_heads, 64).transpose(1, 2)
+    v = v_cache[:, :p + 1].view(B, p + 1, num_heads, 64).transpose(1, 2)
+    w = torch.softmax(q @ k.transpose(2, 3) / 8.0, dim=3)
+    return (w @ v).transpose(1, 2).reshape(B, d)
+
+
+def test_kv_cache_loop_equals_reference_loop_on_cpu():
+    m = gen.build_model("gpt2", Backend.NAIVE_PYTORCH, "cpu", overrides=TINY, seed=6)
+    for prompt, max_tokens in (([5, 6, 7], 40), ([9], 30), ([3] * 16, 17), ([1, 2], 2)):
+        ref = gen.greedy_generate(m, prompt, max_tokens=max_tokens, eos_token=96)
+        g = gen.KVCacheGreedyGenerator(m, 1, max_tokens, eos_token=96, use_graphs=False, decode_fn=_torch_decode)
+        assert g.generate(prompt) == ref
+        assert g.generate(prompt) == ref             # reusable: stale cache rows from the previous run are never read
+    ref2 = gen.greedy_generate(m, [[5, 6, 7], [7, 6, 5]], max_tokens=30, eos_token=96)
+    g2 = gen.KVCacheGreedyGenerator(m, 2, 30, eos_token=96, use_graphs=False, decode_fn=_torch_decode)
+    assert g2.generate([[5, 6, 7], [7, 6, 5]]) == ref2
+
+
 def test_local_hf_checkpoint_loader(tmp_path):
     """HF GPT-2 layout: Conv1D weights stored (in, out) -> transposed on load; LM head tied to wte
     (reference gpt2.py:16-25, :47-56)."""
@@ -207,3 +232,25 @@ def test_hip_graph_generation_identical_to_reference_loop_on_gpu(gpu_device):
     assert gen.greedy_generate(fused, prompt, 128) == [ref[0][:128]]
     gf = gen.BucketedGreedyGenerator(fused, 1, 512, bucket=64, device=gpu_device)
     assert gf.generate(prompt) == ref
+
+
+@pytest.mark.gpu
+def test_kv_cache_generation_on_gpu(gpu_device):
+    """Opt-in KV-cache mode: prompt prefill through the full-sequence kernel, then one captured HIP
+    graph replayed per token around cmhsa_fp32_decode_step.  Same logits mathematically; the one-row GEMMs round
+    differently from the reference loop's T-row GEMMs, so token identity is checked, not assumed: 512 tokens, seeded
+    random weights (low margins), B=1 and B=3, eager step == graph replay."""
+    naive = gen.build_model("gpt2", Backend.NAIVE_PYTORCH, gpu_device, seed=0)
+    hip = gen.build_model("gpt2", Backend.CUSTOM_CUDA, gpu_device, seed=0, fused_gelu=True)
+    prompt = list(gen.REFERENCE_PROMPT_IDS)
+    ref = gen.greedy_generate(naive, prompt, 512)
+    g = gen.KVCacheGreedyGenerator(hip, 1, 512, device=gpu_device)
+    first = g.generate(prompt)
+    again = g.generate(prompt)
+    assert first == again
+    diff = next((i for i, (x, y) in enumerate(zip(first[0], ref[0])) if x != y), None)
+    assert diff is None and len(first[0]) == len(ref[0]), f"first divergence from the cache-less reference loop at {diff}"
+    e = gen.KVCacheGreedyGenerator(hip, 1, 96, device=gpu_device, use_graphs=False)
+    assert e.generate(prompt) == [ref[0][:96]]
+    g3 = gen.KVCacheGreedyGenerator(hip, 3, 128, device=gpu_device)
+    assert g3.generate([prompt] * 3) == [ref[0][:128]] * 3
