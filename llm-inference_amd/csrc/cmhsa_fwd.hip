@@ -8,7 +8,7 @@
 //   * work item = one 32-row query block of one (batch, head); its KV range [0, q_block_end) is cut into
 //     32-key units (causal early exit: nothing past the diagonal is touched, only the diagonal unit is masked);
 //   * a workgroup has W = 8 (one per CU) or 4 (two per CU) wave64s and holds ONE long query block or a PAIR
-//     of a long and a short one (pack_plan(): every wave gets at most ceil(nqb/W) units); the waves of a
+//     of a long and a short one (pack_plan(): every wave gets at most c units); the waves of a
 //     block split its units round-robin (split-KV inside the workgroup), so even B=1, T=1024 fills the chip
 //     with one round of equally long workgroups;
 //   * S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x2_f32: with S^T the query sits on the lane, so
@@ -83,21 +83,22 @@ struct Params {
     int grid_x;                         // gridDim.x: 8 when (b,h)s are pinned to XCDs, else bh (see the kernel)
     unsigned heads_magic, chain_magic;  // floor((2^32-1) / num_heads), floor((2^32-1) / chain): udiv_magic()
     // packing of query blocks into workgroups (pack_plan()):
-    int chain;                          // c: max units any wave processes = ceil(nqb / kWaves)
+    int chain;                          // c: max units any wave processes (>= ceil(nqb / kWaves))
     int n_paired;                       // R: query blocks 1..R units long are paired n <-> R+1-n
     int n_alone;                        // nqb - R: the longest query blocks get a workgroup each
 };
 
-// Packing plan.  A query block with n units gets g(n) = ceil(n / c) waves, so that no wave runs more than
-// c = ceil(nqb / kWaves) units.  The R = min(nqb, c*(kWaves-1)) shortest blocks are paired n <-> R+1-n:
-// g(n) + g(R+1-n) == kWaves exactly (for R = c*(kWaves-1)), i.e. every paired workgroup has all its waves
-// busy with R+1 units in total; the nqb-R longest blocks each need all kWaves waves.  One round of
+// Packing plan.  A query block with n units gets g(n) = ceil(n / c) waves, so that no wave runs more than c units
+// (c >= ceil(nqb / kWaves), so that the longest block fits in one workgroup).  The R = min(nqb, c*(kWaves-1))
+// shortest blocks are paired n <-> R+1-n: g(n) + g(R+1-n) <= kWaves (== for R = c*(kWaves-1)), i.e. a paired
+// workgroup has R+1 units in total; the nqb-R longest blocks each need all kWaves waves.  One round of
 // equally long workgroups instead of a tail of short ones that each hold a whole CU.
-struct PackPlan { int chain, n_paired, n_alone, wgs_per_bh; };
-inline PackPlan pack_plan(int nqb, int waves) {
+struct PackPlan { int waves, chain, n_paired, n_alone, wgs_per_bh; };
+inline PackPlan pack_plan(int nqb, int waves, int chain = 0) {
     PackPlan pl;
-    pl.chain = (nqb + waves - 1) / waves;
-    pl.n_paired = min(nqb, pl.chain * (waves - 1));
+    pl.waves = waves;
+    pl.chain = chain > 0 ? chain : (nqb + waves - 1) / waves;
+    pl.n_paired = (int)min((int64_t)nqb, (int64_t)pl.chain * (waves - 1));
     pl.n_alone = nqb - pl.n_paired;
     pl.wgs_per_bh = pl.n_alone + (pl.n_paired + 1) / 2;
     return pl;
@@ -500,23 +501,45 @@ hipError_t launch(const Params &p, dim3 grid, void *stream) {
     return hipSuccess;
 }
 
-// Waves per workgroup.  8-wave workgroups (one per CU) halve the longest query block's chain: they win while
-// the packed grid fits in one round of CUs (BASELINE config 2: 216 workgroups, 23.9 vs 24.7 us); beyond that
-// two co-resident 4-wave workgroups per CU hide each other's prologue and merge (B=16 T=1024: 288 vs 315 us).
-// Measured on MI355X with tools/cmhsa_bench, see profiles/.
-// CMHSA_WAVES=4|8 in the environment overrides (read once; for experiments).
-int choose_waves(int64_t bh, int nqb) {
+// Workgroup shape W and chain cap c.  8-wave workgroups (one per CU) halve the longest query block's chain: they
+// win while the packed grid fits in one round of CUs (BASELINE config 2: 216 workgroups, 23.9 vs 24.7 us); beyond
+// that two co-resident 4-wave workgroups per CU hide each other's prologue and merge (B=16 T=1024: 288 vs 315 us).
+// In between -- a grid of 1..2 rounds at the smallest c -- a LARGER c packs the same work into fewer, longer
+// 8-wave workgroups that fit one round (B=1 H=16 T=1024: 18 workgroups per head at c=4 are 288 > 256 CUs, 16 at
+// c=5 are exactly 256).  Among the single-round candidates the estimate
+//     cycles = fixed + (units on the busiest SIMD) * cycles_per_unit
+// picks; without a single-round candidate: W=4 at its smallest c.  Constants measured on MI355X
+// (tools/cmhsa_bench_stamps).  CMHSA_WAVES=4|8 in the environment forces W (experiments).
+PackPlan choose_plan(int64_t bh, int nqb) {
     static const int forced = [] {
         const char *e = getenv("CMHSA_WAVES");
         return e ? atoi(e) : 0;
     }();
-    if (forced == 4 || forced == 8) return forced;
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    return bh * pack_plan(nqb, 8).wgs_per_bh <= cus ? 8 : 4;
+    if (forced == 4 || forced == 8) return pack_plan(nqb, forced);
+    constexpr double kFixed = 8000.0, kUnit = 5000.0;
+    PackPlan best = pack_plan(nqb, 4);
+    double best_cycles = -1.0;
+    for (int waves = 8; waves >= 4; waves -= 4) {
+        const int c_min = (nqb + waves - 1) / waves;
+        for (int c = c_min; c <= nqb && c < c_min + 64; ++c) {
+            const PackPlan pl = pack_plan(nqb, waves, c);
+            const int64_t wgs = bh * pl.wgs_per_bh;
+            if (wgs > (int64_t)cus * (waves == 8 ? 1 : 2)) continue;              // not a single round
+            const int wg_units = pl.n_alone ? nqb : pl.n_paired + 1;              // the longest workgroup
+            // 8 waves: two per SIMD; 4 waves: one per SIMD, and a second workgroup shares the CU once there are more than CUs
+            const int per_wave = min(c, (wg_units + waves - 1) / waves);
+            const int simd_units = waves == 8 ? min(2 * c, (wg_units + 3) / 4) : per_wave * (wgs > cus ? 2 : 1);
+            const double cycles = kFixed + simd_units * kUnit;
+            if (best_cycles < 0 || cycles < best_cycles) { best = pl; best_cycles = cycles; }   // ties: 8 waves, smaller c
+            if (pl.n_alone == 0) break;                                           // larger c changes nothing any more
+        }
+    }
+    return best;
 }
 
 }  // namespace
@@ -574,8 +597,8 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     const int64_t max_rs = q_row_stride > k_row_stride ? q_row_stride : k_row_stride;
     if ((max_rs > v_row_stride ? max_rs : v_row_stride) > (1LL << 24)) return CMHSA_ERR_TOO_LARGE;
 
-    const int waves = choose_waves(bh, (int)nqb);
-    const PackPlan pl = pack_plan((int)nqb, waves);
+    const PackPlan pl = choose_plan(bh, (int)nqb);
+    const int waves = pl.waves;
     // grid = (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8
     // or too large for gridDim.z.  HIP limits: y, z <= 65535, and x * threads < 2^32.
     const bool xcd_map = bh % 8 == 0 && bh / 8 <= 65535;

@@ -77,7 +77,9 @@ def test_sweep_randn_against_f64_oracle(gpu_device):
     assert worst <= TOL, worst
 
 
-@pytest.mark.parametrize("d_model,H", [(768, 12), (1024, 16), (1280, 20), (1600, 25), (64, 1), (192, 3)])
+@pytest.mark.parametrize("d_model,H", [(768, 12), (1024, 16), (1280, 20), (1600, 25), (64, 1), (192, 3),
+                                        (832, 13), (960, 15), (1088, 17)])   # 13..17 heads: grids around one round of CUs,
+                                                                             # where the plan picks a larger chain cap
 def test_all_model_widths_t1024_strided(d_model, H, gpu_device):
     """T=1024 (the reference's max context), every GPT-2 width (CMHSA.cu:435-449) plus odd head
     counts, inputs as QKV slices.  Checked on a head subset against the f64 oracle."""
