@@ -14,7 +14,7 @@
 //   * S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x2_f32: with S^T the query sits on the lane, so
 //     softmax statistics are per-lane scalars and the S^T accumulator registers are, as they stand, the B
 //     operand of the PV product (no LDS round trip, no lane shuffles);
-//   * K: coalesced buffer loads -> staging registers -> the wave's private, double-buffered, XOR-swizzled
+//   * K: coalesced buffer loads -> staging registers (one unit ahead) -> the wave's private, XOR-swizzled
 //     LDS unit -> ds_read_b128 fragments; V: straight from global into the MFMA A-operand layout, one
 //     unit ahead; the query block is fetched once per workgroup into shared LDS.  The main loop has no
 //     barrier and no branch inside the MFMA chains;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     const float *kg = p.k + b * p.k_bs + (int64_t)h * kHeadDim;
     const float *vg = p.v + b * p.v_bs + (int64_t)h * kHeadDim;
 
-    float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: K[0] | K[1] (double-buffered)
+    float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: its current K unit (8 KiB); later its merge image
     float *qlds_all = lds + kWaves * kWaveLdsFloats;                   // shared: query block of A | of B,
     float *qlds = qlds_all + seg * kUnitFloats;                        // pre-scaled, K-style swizzle
 
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         const int voff = half * 4 * vrs4 + l31 * 8;                                       // V: straight into MFMA layout
         const float *krow0 = wlds + l31 * kHeadDim;
         const int sw = l31 & 15;
-        auto kfrag = [&](int buf, int c) {
-            return *reinterpret_cast<const f32x4 *>(krow0 + buf * kUnitFloats + (((2 * c + half) ^ sw) << 2));
+        auto kfrag = [&](int c) {
+            return *reinterpret_cast<const f32x4 *>(krow0 + (((2 * c + half) ^ sw) << 2));
         };
 
         // All per-lane load offsets are computed once: VALU instructions are NOT free beside fp32 MFMAs (they
@@ -290,8 +290,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) qf[4 * c + j] = t[j];
         }
-        f32x4 kcur = kfrag(0, 0), knext = kfrag(0, 1);
-        int cur = 0;
+        f32x4 kcur = kfrag(0), knext = kfrag(1);
         STAMP(1);
 
         // One unit = QK chain, softmax, PV chain.  `first` (compile time): the wave's first unit, whose QK chain
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             for (int c = 0; c < 8; ++c) {
                 const f32x4 kk = kcur;
                 kcur = knext;
-                if (c + 2 < 8) knext = kfrag(cur, c + 2);
+                if (c + 2 < 8) knext = kfrag(c + 2);
                 if constexpr (kFirst) {
                     vreg[2 * c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc0, voffs[2 * c], 0, 0));
                     vreg[2 * c + 1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vsrc0, voffs[2 * c + 1], 0, 0));
@@ -374,22 +373,24 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             //      k-step r pairs keys acc_row(r) (lanes 0-31) and acc_row(r)+4 (lanes 32-63), which is exactly
             //      where accumulator register r of S^T holds them: P feeds the B operand as it stands.
             //      Interleaved with the chain (program order = issue order, one item per MFMA pair):
-            //        steps 0-7  : staged K(u+1) registers -> the other LDS buffer
+            //        steps 0-7  : staged K(u+1) registers -> the wave's LDS unit.  ONE buffer is enough: every
+            //                     fragment of K(u) was read before the QK chain's last MFMAs were issued, and a
+            //                     wave's LDS operations execute in order (a second buffer only cost address VALU:
+            //                     measured -3 % time without it)
             //        steps 8-15 : K(u+2) global -> staging registers;  steps 13,14: first K(u+1) fragments ----
             //      Everything is unconditional (past the last unit the descriptors have zero records and the
-            //      LDS traffic goes to the idle buffer), so the chain stays one basic block.
+            //      LDS unit receives zeros nobody reads), so the chain stays one basic block.
             const __amdgpu_buffer_rsrc_t ksrc2 = unit_rsrc(kg, p.k_rs, (u + 2 * seg_waves) * kKeyUnit, N, u + 2 * seg_waves < n_units);
             const __amdgpu_buffer_rsrc_t vsrc1 = unit_rsrc(vg, p.v_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < n_units);
-            float *knew = wlds + (cur ^ 1) * kUnitFloats;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (r < 8) {
                     const int row = 4 * r + sub;
-                    *reinterpret_cast<f32x4 *>(knew + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = kst[r];
+                    *reinterpret_cast<f32x4 *>(wlds + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = kst[r];
                 } else {
                     kst[r - 8] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ksrc2, koffs[r - 8], 0, 0));
-                    if (r == 13) kcur = kfrag(cur ^ 1, 0);
-                    if (r == 14) knext = kfrag(cur ^ 1, 1);
+                    if (r == 13) kcur = kfrag(0);
+                    if (r == 14) knext = kfrag(1);
                 }
                 if (r == 8) {   // all K(u+1) stores are queued: order them before this wave's later LDS reads
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -407,7 +408,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             STAMP(stamp_i + 3);
             stamp_i += 4;
 #endif
-            cur ^= 1;
         };
 
         unit(wloc, std::true_type{});            // every active wave owns at least one unit (wloc < seg_waves <= n_units)
