@@ -29,7 +29,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 #include <type_traits>
 
 #include "cmhsa.h"
@@ -48,8 +52,13 @@ constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
 //   8 -> one 128-KiB workgroup per CU (two of its waves per SIMD): shortest chain per query block
 //   4 -> two 64-KiB workgroups per CU: prologue/merge of one overlaps the main loop of the other
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
-constexpr int kWaveLdsFloats = 2 * kUnitFloats;           // K + V = 16 KiB per wave
-constexpr int lds_bytes(int waves) { return (waves * kWaveLdsFloats + 2 * kUnitFloats) * 4; }   // + two shared, pre-scaled Q blocks
+constexpr int kMaxSeg = 4;                                // query blocks ("segments") one workgroup can hold (template kSegs: 2 or 4)
+constexpr int kMaxTableWgs = 64;                          // workgroups per (b,h) an explicit segment table can describe
+// LDS: [kWaves][8 KiB] each wave's K unit (later its merge image) | [kSegs][8 KiB] pre-scaled query blocks |
+//      [kWaves][m[32] | l[32]] softmax statistics for the merge
+constexpr int lds_floats_q(int waves) { return waves * kUnitFloats; }
+constexpr int lds_floats_ml(int waves, int segs) { return (waves + segs) * kUnitFloats; }
+constexpr int lds_bytes(int waves, int segs) { return (lds_floats_ml(waves, segs) + waves * 64) * 4; }   // <= 98 KiB (8 waves), 65 KiB (4)
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
 constexpr float kRescaleThreshold = 16.f;                 // lazy rescale: keep the old max while it is within 2^16
 
@@ -86,6 +95,10 @@ struct Params {
     int chain;                          // c: max units any wave processes (>= ceil(nqb / kWaves))
     int n_paired;                       // R: query blocks 1..R units long are paired n <-> R+1-n
     int n_alone;                        // nqb - R: the longest query blocks get a workgroup each
+    // explicit plan (use_table != 0; choose_plan()): workgroup j of every (b,h) holds the query blocks whose unit
+    // counts are the bytes of seg_table[j] (low byte first, 0 = none; a block with n units is block index n-1)
+    int use_table;
+    unsigned seg_table[kMaxTableWgs];
 };
 
 // Packing plan.  A query block with n units gets g(n) = ceil(n / c) waves, so that no wave runs more than c units
@@ -160,7 +173,8 @@ __device__ __forceinline__ int udiv_magic(int n, int d, unsigned magic) {
     return (int)(q + (((unsigned)n - q * (unsigned)d) >= (unsigned)d ? 1u : 0u));
 }
 
-template <int kWaves>
+// kSegs = 2: the analytic plan (one block or a pair per workgroup); 4: an explicit table (Params::seg_table).
+template <int kWaves, int kSegs>
 __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     // before the first global load could be issued.
     asm volatile("" ::"s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs), "s"(p.v_rs), "s"(p.o_rs));
     asm volatile("" ::"s"(p.q_bs), "s"(p.k_bs), "s"(p.v_bs), "s"(p.o_bs), "s"(p.seq_len), "s"(p.num_heads), "s"(p.nqb),
-                 "s"(p.grid_x), "s"(p.heads_magic), "s"(p.chain_magic), "s"(p.chain), "s"(p.n_paired), "s"(p.n_alone));
+                 "s"(p.grid_x), "s"(p.heads_magic), "s"(p.chain_magic), "s"(p.chain), "s"(p.n_paired), "s"(p.n_alone), "s"(p.use_table));
     STAMP(124);
 
     // ---- grid -> (batch*head, workgroup j of that head).  Workgroups are dispatched in linear order, x fastest,
@@ -190,26 +204,36 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     //      stay in that XCD's L2), with grid = (bh, wgs_per_bh, 1) otherwise; either way j = 0 (heaviest) first.
     const int bh = blockIdx.z * p.grid_x + blockIdx.x;
     const int j = blockIdx.y;
-    // ---- workgroup j -> one or two query blocks ("segments"), this wave -> (segment, local wave index) ----
-    int n_a, n_b;                                 // units (= query block index + 1) of segments A and B; 0 = none
-    if (j < p.n_alone) {
-        n_a = p.nqb - j;
-        n_b = 0;
-    } else {
-        const int t = j - p.n_alone;
-        n_a = p.n_paired - t;
-        n_b = t + 1;
-        if (n_b == n_a) n_b = 0;                  // middle block of an odd count: alone with half the waves
+    // ---- workgroup j -> up to kSegs query blocks ("segments"), this wave -> (segment, local wave index) ----
+    int seg_n[kSegs];                           // units (= query block index + 1) of each segment; 0 = none
+    if (kSegs > 2) {                              // explicit plan (only this variant is launched with a table)
+        const unsigned e = p.seg_table[j];
+#pragma unroll
+        for (int i = 0; i < kSegs; ++i) seg_n[i] = (e >> (8 * i)) & 255;
+    } else {                                      // analytic plan: the longest blocks alone, the others paired n <-> R+1-n
+#pragma unroll
+        for (int i = 0; i < kSegs; ++i) seg_n[i] = 0;
+        if (j < p.n_alone) {
+            seg_n[0] = p.nqb - j;
+        } else {
+            const int t = j - p.n_alone;
+            seg_n[0] = p.n_paired - t;
+            if (t + 1 != seg_n[0]) seg_n[1] = t + 1;   // (middle block of an odd count: alone with half the waves)
+        }
     }
-    const int g_a = udiv_magic(n_a + p.chain - 1, p.chain, p.chain_magic);             // waves of segment A: [0, g_a)
-    const int g_b = n_b ? udiv_magic(n_b + p.chain - 1, p.chain, p.chain_magic) : 0;   // of segment B: [g_a, g_a + g_b)
-    int n_units, seg_w0, seg_waves, seg;          // units of my query block; first wave / wave count of my segment
-    if (wave < g_a) {
-        seg = 0; n_units = n_a; seg_w0 = 0; seg_waves = g_a;
-    } else if (wave < g_a + g_b) {
-        seg = 1; n_units = n_b; seg_w0 = g_a; seg_waves = g_b;
-    } else {
-        seg = 0; n_units = 0; seg_w0 = wave; seg_waves = 1;       // idle wave: joins the barriers and the row work only
+    int seg_lo[kSegs], seg_hi[kSegs];         // waves [seg_lo, seg_hi) work on segment i: ceil(n / c) of them
+    int n_units = 0, seg_w0 = wave, seg_waves = 1, seg = 0, n_seg = 0;   // defaults = idle wave: barriers and row work only
+    {
+        int w0 = 0;
+#pragma unroll
+        for (int i = 0; i < kSegs; ++i) {
+            const int g = seg_n[i] ? udiv_magic(seg_n[i] + p.chain - 1, p.chain, p.chain_magic) : 0;
+            seg_lo[i] = w0;
+            seg_hi[i] = w0 + g;
+            if (wave >= w0 && wave < w0 + g) { seg = i; n_units = seg_n[i]; seg_w0 = w0; seg_waves = g; }
+            n_seg += seg_n[i] ? 1 : 0;
+            w0 += g;
+        }
     }
     const int wloc = wave - seg_w0;
     const bool active = n_units > 0;
@@ -221,9 +245,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     const float *kg = p.k + b * p.k_bs + (int64_t)h * kHeadDim;
     const float *vg = p.v + b * p.v_bs + (int64_t)h * kHeadDim;
 
-    float *wlds = lds + wave * kWaveLdsFloats;   // private to this wave: its current K unit (8 KiB); later its merge image
-    float *qlds_all = lds + kWaves * kWaveLdsFloats;                   // shared: query block of A | of B,
+    float *wlds = lds + wave * kUnitFloats;      // private to this wave: its current K unit (8 KiB); later its merge image
+    float *qlds_all = lds + lds_floats_q(kWaves);                      // shared: the segments' query blocks,
     float *qlds = qlds_all + seg * kUnitFloats;                        // pre-scaled, K-style swizzle
+    float *ml_all = lds + lds_floats_ml(kWaves, kSegs);                       // [wave][m[32] | l[32]]
 
     // per-lane byte offsets inside a unit
     const int sub = lane >> 4, chunk = lane & 15;
@@ -238,13 +263,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     f32x4 kst[8];                    // K staging registers (always one unit ahead of LDS)
     load_unit(unit_rsrc(kg, p.k_rs, wloc * kKeyUnit, N, active), koff, kstep, kst);
     {
-        constexpr int kQIters = 16 / kWaves;
+        constexpr int kQIters = kSegs * 8 / kWaves;
         f32x4 qst[kQIters];
 #pragma unroll
         for (int i = 0; i < kQIters; ++i) {
-            const int rg = wave + i * kWaves, sg = rg >> 3, row = 4 * (rg & 7) + sub;
-            const int sq0 = ((sg && n_b ? n_b : n_a) - 1) * kQBlock;
-            const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, sq0, N, !sg || n_b);
+            const int rg = wave + i * kWaves, sg = rg >> 3, row = 4 * (rg & 7) + sub;    // sg is a compile-time constant
+            const int sq0 = (max(seg_n[sg], 1) - 1) * kQBlock;
+            const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, sq0, N, seg_n[sg] != 0);
             qst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (row * (int)p.q_rs + chunk * 4) * 4, 0, 0));
         }
         STAMP(121);
@@ -421,10 +446,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     // ---- merge the split-KV partials of each segment: ONE barrier, no transposition.
     //      Every active wave publishes its un-normalised O accumulators in their native MFMA layout, as 8
     //      float4 "pairs" per lane -- pair pi = {o0[2pi], o1[2pi], o0[2pi+1], o1[2pi+1]} = 4 consecutive d
-    //      of the lane's query -- plus its (m, l).  After the barrier the 8 (or 16) (segment, pair) items go
+    //      of the lane's query -- plus its (m, l).  After the barrier the 8 (segment, pair) items per segment go
     //      round-robin over ALL waves: an item reads the pair of every wave of its segment, weights it with
     //      exp2(m_w - m_tot), divides by the merged l and stores one float4 per lane straight to O. ----
-    constexpr int kMlOff = 8 * 64 * 4;                   // m[32] | l[32] sit behind the 8 KiB of pairs
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (active) {
@@ -435,17 +459,20 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             pub[pi * 64 + lane] = t;
         }
         if (lane < 32) {
-            wlds[kMlOff + lane] = m_run;
-            wlds[kMlOff + 32 + lane] = l_run;
+            ml_all[wave * 64 + lane] = m_run;
+            ml_all[wave * 64 + 32 + lane] = l_run;
         }
     }
     __syncthreads();
     STAMP(120);
     {
         float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
-        for (int item = wave; item < (n_b ? 16 : 8); item += kWaves) {       // wave-uniform trip count
+        for (int item = wave; item < 8 * n_seg; item += kWaves) {            // wave-uniform trip count
             const int sg = item >> 3, pi = item & 7;
-            const int w_lo = sg ? g_a : 0, w_hi = sg ? g_a + g_b : g_a;
+            int w_lo = 0, w_hi = 0, n_sg = 1;
+#pragma unroll
+            for (int i = 0; i < kSegs; ++i)
+                if (i == sg) { w_lo = seg_lo[i]; w_hi = seg_hi[i]; n_sg = seg_n[i]; }
             // wave-uniform bit masks instead of selects keep the LDS reads unconditional and back to back
             // (hipcc turns a uniform select of a load into a branch with a full lgkmcnt(0) wait per read)
             float mw[kWaves], lw[kWaves];
@@ -454,9 +481,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) {
                 const unsigned mine = (w >= w_lo && w < w_hi) ? 0xffffffffu : 0u;
-                const float *base = lds + w * kWaveLdsFloats;
-                const float mv = base[kMlOff + l31], lv = base[kMlOff + 32 + l31];
-                const u32x4 ov = *reinterpret_cast<const u32x4 *>(base + (pi * 64 + lane) * 4);
+                const float mv = ml_all[w * 64 + l31], lv = ml_all[w * 64 + 32 + l31];
+                const u32x4 ov = *reinterpret_cast<const u32x4 *>(lds + w * kUnitFloats + (pi * 64 + lane) * 4);
                 mw[w] = __uint_as_float((__float_as_uint(mv) & mine) | (~mine & 0xff800000u));   // -inf when not mine
                 lw[w] = __uint_as_float(__float_as_uint(lv) & mine);
                 ow[w] = __builtin_bit_cast(f32x4, ov & mine);
@@ -471,75 +497,183 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 acc += ow[w] * f;
             }
             acc *= 1.0f / l_tot;
-            const int row = ((sg ? n_b : n_a) - 1) * kQBlock + l31;
+            const int row = (n_sg - 1) * kQBlock + l31;
             const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);       // = 2 * (acc_row(2 pi) + 4 half)
             if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
         }
     }
 #ifdef CMHSA_STAMPS
     STAMP(3);
-    if (g_block_times && threadIdx.x == 0) g_block_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (g_block_times && threadIdx.x == 0) g_block_times[2 * lin_block + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
-std::atomic<int> g_attr_set[2][64];  // per variant and device: dynamic-LDS limit raised once, not per call
+std::atomic<int> g_attr_set[4][64];  // per variant and device: dynamic-LDS limit raised once, not per call
 
-template <int kWaves>
+template <int kWaves, int kSegs>
 hipError_t launch(const Params &p, dim3 grid, void *stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kWaves == 8][dev] : nullptr;
+    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[(kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
     if (!flag || !flag->load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kWaves));
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kWaves, kSegs));
         if (e != hipSuccess) return e;
         if (flag) flag->store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(cmhsa_fwd_kernel<kWaves>, grid, dim3(kWaves * 64), lds_bytes(kWaves),
-                       static_cast<hipStream_t>(stream), p);
+    void (*kernel)(Params) = cmhsa_fwd_kernel<kWaves, kSegs>;
+    hipLaunchKernelGGL(kernel, grid, dim3(kWaves * 64), lds_bytes(kWaves, kSegs), static_cast<hipStream_t>(stream), p);
     return hipSuccess;
 }
 
-// Workgroup shape W and chain cap c.  8-wave workgroups (one per CU) halve the longest query block's chain: they
-// win while the packed grid fits in one round of CUs (BASELINE config 2: 216 workgroups, 23.9 vs 24.7 us); beyond
-// that two co-resident 4-wave workgroups per CU hide each other's prologue and merge (B=16 T=1024: 288 vs 315 us).
-// In between -- a grid of 1..2 rounds at the smallest c -- a LARGER c packs the same work into fewer, longer
-// 8-wave workgroups that fit one round (B=1 H=16 T=1024: 18 workgroups per head at c=4 are 288 > 256 CUs, 16 at
-// c=5 are exactly 256).  Among the single-round candidates the estimate
-//     cycles = fixed + (units on the busiest SIMD) * cycles_per_unit
-// picks; without a single-round candidate: W=4 at its smallest c.  Constants measured on MI355X
-// (tools/cmhsa_bench_stamps).  CMHSA_WAVES=4|8 in the environment forces W (experiments).
-PackPlan choose_plan(int64_t bh, int nqb) {
-    static const int forced = [] {
-        const char *e = getenv("CMHSA_WAVES");
-        return e ? atoi(e) : 0;
-    }();
+// ---- plan selection (host) ---------------------------------------------------------------------------------------
+// A plan = (waves per workgroup W, chain cap c, which query blocks each workgroup of a (b,h) holds).  Two families:
+//   analytic  pack_plan(): a block alone or a pair n <-> R+1-n; decoded in the kernel from three integers; any size;
+//   table     up to 4 blocks per workgroup, packed greedily (longest block first into the feasible workgroup with
+//             the fewest units), handed to the kernel as Params::seg_table; nqb <= 255 and <= 64 workgroups per (b,h).
+// Grids that fit the chip in ONE round are where the choice matters (measured, tools/sweep_plans.sh: H = 16, 20 at
+// B=1, T=1024 gain 30 % / 10 %): among the single-round candidates the cheapest by
+//     cycles = kFixed + (units on the busiest SIMD of the longest workgroup) * kUnit      (8 k + n * 5 k, measured)
+// wins; an 8-wave workgroup owns its CU (two of its waves per SIMD), two 4-wave workgroups share one.  Grids of
+// several rounds run within +-3 % of each other under every plan tried, so they keep the analytic plan with 4-wave
+// workgroups at the smallest c (two co-resident workgroups hide each other's prologue and merge).
+// Environment overrides for experiments (read once): CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1.
+struct Plan {
+    PackPlan pp;
+    bool use_table = false;
+    int n_wgs = 0;                               // workgroups per (b,h)
+    bool single_round = false;                   // the whole grid is resident at once
+    unsigned char segs[kMaxTableWgs][kMaxSeg];   // table plans: unit counts per workgroup, 0 = none
+    double cycles = 0.0;
+};
+
+// units on the busiest SIMD of a workgroup holding blocks n[0..k): block i gets ceil(n_i/c) consecutive waves, its
+// units go round-robin over them; waves w and w+4 share a SIMD
+int busiest_simd(const int *n, int k, int c, int waves) {
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w = 0;
+    for (int i = 0; i < k; ++i) {
+        if (!n[i]) continue;
+        const int g = (n[i] + c - 1) / c;
+        for (int t = 0; t < g && w < 8; ++t, ++w) load[w] = n[i] / g + (t < n[i] % g ? 1 : 0);
+    }
+    int m = 0;
+    for (int sidx = 0; sidx < 4; ++sidx) m = max(m, load[sidx] + (waves == 8 ? load[sidx + 4] : 0));
+    return m;
+}
+
+void price(Plan &pl, const int (*wg_blocks)[kMaxSeg], int n_wgs, int64_t bh, int cus) {
+    constexpr double kFixed = 8000.0, kUnit = 5000.0;
+    const int waves = pl.pp.waves;
+    const int64_t wgs = bh * n_wgs;
+    const bool shared = waves == 4 && wgs > cus;                    // a second 4-wave workgroup on the same CU
+    double longest = 0.0;
+    for (int j = 0; j < n_wgs; ++j) {
+        const int l = busiest_simd(wg_blocks[j], kMaxSeg, pl.pp.chain, waves);
+        longest = fmax(longest, kFixed + (shared ? 2.0 : 1.0) * l * kUnit);
+    }
+    pl.n_wgs = n_wgs;
+    pl.single_round = wgs <= (int64_t)cus * (waves == 8 ? 1 : 2);
+    pl.cycles = longest;                 // meaningful for single-round grids only, the only ones compared
+}
+
+bool table_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
+    if (nqb > 255) return false;
+    int blocks[kMaxTableWgs][kMaxSeg] = {}, units[kMaxTableWgs] = {}, free_waves[kMaxTableWgs], nseg[kMaxTableWgs] = {};
+    int n_wgs = 0;
+    for (int n = nqb; n >= 1; --n) {
+        const int g = (n + c - 1) / c;
+        int pick = -1;
+        for (int j = 0; j < n_wgs; ++j)
+            if (free_waves[j] >= g && nseg[j] < kMaxSeg && (pick < 0 || units[j] < units[pick])) pick = j;
+        if (pick < 0) {
+            if (n_wgs == kMaxTableWgs) return false;
+            pick = n_wgs++;
+            free_waves[pick] = waves;
+        }
+        blocks[pick][nseg[pick]++] = n;
+        units[pick] += n;
+        free_waves[pick] -= g;
+    }
+    // heaviest workgroups first (blockIdx.y = 0 is dispatched first): selection sort, n_wgs <= 64
+    for (int i = 0; i < n_wgs; ++i) {
+        int m = i;
+        for (int j = i + 1; j < n_wgs; ++j) if (units[j] > units[m]) m = j;
+        if (m != i) {
+            for (int t = 0; t < kMaxSeg; ++t) { const int x = blocks[i][t]; blocks[i][t] = blocks[m][t]; blocks[m][t] = x; }
+            const int x = units[i]; units[i] = units[m]; units[m] = x;
+        }
+    }
+    pl.pp = pack_plan(nqb, waves, c);
+    pl.pp.wgs_per_bh = n_wgs;
+    pl.use_table = true;
+    for (int j = 0; j < n_wgs; ++j)
+        for (int t = 0; t < kMaxSeg; ++t) pl.segs[j][t] = (unsigned char)blocks[j][t];
+    price(pl, blocks, n_wgs, bh, cus);
+    return true;
+}
+
+void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
+    pl.pp = pack_plan(nqb, waves, c);
+    pl.use_table = false;
+    // priced from its closed form: the alone blocks nqb, nqb-1, ..., then the pairs (R - t, t + 1)
+    std::vector<int> flat((size_t)pl.pp.wgs_per_bh * kMaxSeg, 0);
+    int (*blocks)[kMaxSeg] = reinterpret_cast<int (*)[kMaxSeg]>(flat.data());
+    for (int j = 0; j < pl.pp.wgs_per_bh; ++j) {
+        if (j < pl.pp.n_alone) blocks[j][0] = nqb - j;
+        else { const int t = j - pl.pp.n_alone; blocks[j][0] = pl.pp.n_paired - t; if (t + 1 != blocks[j][0]) blocks[j][1] = t + 1; }
+    }
+    price(pl, blocks, pl.pp.wgs_per_bh, bh, cus);
+}
+
+Plan choose_plan(int64_t bh, int nqb) {
+    static const int forced_waves = [] { const char *e = getenv("CMHSA_WAVES"); return e ? atoi(e) : 0; }();
+    static const int forced_chain = [] { const char *e = getenv("CMHSA_CHAIN"); return e ? atoi(e) : 0; }();
+    static const int forced_table = [] { const char *e = getenv("CMHSA_TABLE"); return e ? atoi(e) : -1; }();
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    if (forced == 4 || forced == 8) return pack_plan(nqb, forced);
-    constexpr double kFixed = 8000.0, kUnit = 5000.0;
-    PackPlan best = pack_plan(nqb, 4);
-    double best_cycles = -1.0;
+    Plan best;
+    bool have = false;
     for (int waves = 8; waves >= 4; waves -= 4) {
+        if (forced_waves && forced_waves != waves) continue;
         const int c_min = (nqb + waves - 1) / waves;
-        for (int c = c_min; c <= nqb && c < c_min + 64; ++c) {
-            const PackPlan pl = pack_plan(nqb, waves, c);
-            const int64_t wgs = bh * pl.wgs_per_bh;
-            if (wgs > (int64_t)cus * (waves == 8 ? 1 : 2)) continue;              // not a single round
-            const int wg_units = pl.n_alone ? nqb : pl.n_paired + 1;              // the longest workgroup
-            // 8 waves: two per SIMD; 4 waves: one per SIMD, and a second workgroup shares the CU once there are more than CUs
-            const int per_wave = min(c, (wg_units + waves - 1) / waves);
-            const int simd_units = waves == 8 ? min(2 * c, (wg_units + 3) / 4) : per_wave * (wgs > cus ? 2 : 1);
-            const double cycles = kFixed + simd_units * kUnit;
-            if (best_cycles < 0 || cycles < best_cycles) { best = pl; best_cycles = cycles; }   // ties: 8 waves, smaller c
-            if (pl.n_alone == 0) break;                                           // larger c changes nothing any more
+        // nothing changes any more once every block fits in one wave; nqb > 4096: only the smallest c (pricing is O(nqb))
+        const int c_max = forced_chain ? max(forced_chain, c_min) : (nqb > 4096 ? c_min : min(nqb, 4 * c_min + 4));
+        for (int c = forced_chain ? c_max : c_min; c <= c_max; ++c) {
+            for (int table = 0; table <= 1; ++table) {
+                if (forced_table >= 0 && forced_table != table) continue;
+                Plan pl;
+                if (table) { if (!table_plan(pl, nqb, waves, c, bh, cus)) continue; }
+                else analytic_plan(pl, nqb, waves, c, bh, cus);
+                if (!pl.single_round && !(forced_waves || forced_chain || forced_table >= 0)) continue;
+                // ties: keep the earlier candidate (8 waves before 4, small c before large, analytic before table)
+                if (!have || pl.cycles < best.cycles * 0.98) { best = pl; have = true; }
+            }
         }
     }
+    if (!have) analytic_plan(best, nqb, 4, (nqb + 3) / 4, bh, cus);      // several rounds (or an impossible forced combination)
+    static const bool verbose = getenv("CMHSA_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "cmhsa plan: bh=%lld nqb=%d -> waves=%d chain=%d %s wgs/bh=%d est=%.0f cycles\n", (long long)bh, nqb,
+                best.pp.waves, best.pp.chain, best.use_table ? "table" : "analytic", best.n_wgs, best.cycles);
     return best;
+}
+
+// choose_plan() prices dozens of candidates; calls repeat the same few shapes, so the result is memoised
+const Plan &cached_plan(int64_t bh, int nqb) {
+    struct Entry { int64_t bh; int nqb; Plan plan; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry &e : cache)
+        if (e.bh == bh && e.nqb == nqb) return e.plan;
+    if (cache.size() >= 256) cache.clear();
+    cache.reserve(256);                              // references handed out stay valid until the next clear
+    cache.push_back(Entry{bh, nqb, choose_plan(bh, nqb)});
+    return cache.back().plan;
 }
 
 }  // namespace
@@ -597,7 +731,8 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     const int64_t max_rs = q_row_stride > k_row_stride ? q_row_stride : k_row_stride;
     if ((max_rs > v_row_stride ? max_rs : v_row_stride) > (1LL << 24)) return CMHSA_ERR_TOO_LARGE;
 
-    const PackPlan pl = choose_plan(bh, (int)nqb);
+    const Plan plan = cached_plan(bh, (int)nqb);          // copied: the cache may be cleared by another thread
+    const PackPlan &pl = plan.pp;
     const int waves = pl.waves;
     // grid = (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8
     // or too large for gridDim.z.  HIP limits: y, z <= 65535, and x * threads < 2^32.
@@ -617,8 +752,13 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     p.heads_magic = 0xffffffffu / (unsigned)num_heads;
     p.chain_magic = 0xffffffffu / (unsigned)pl.chain;
     p.chain = pl.chain; p.n_paired = pl.n_paired; p.n_alone = pl.n_alone;
+    p.use_table = plan.use_table ? 1 : 0;
+    if (plan.use_table)
+        for (int j = 0; j < plan.n_wgs; ++j)
+            p.seg_table[j] = plan.segs[j][0] | (plan.segs[j][1] << 8) | (plan.segs[j][2] << 16) | ((unsigned)plan.segs[j][3] << 24);
 
-    hipError_t e = waves == 8 ? launch<8>(p, grid, stream) : launch<4>(p, grid, stream);
+    hipError_t e = p.use_table ? (waves == 8 ? launch<8, 4>(p, grid, stream) : launch<4, 4>(p, grid, stream))
+                               : (waves == 8 ? launch<8, 2>(p, grid, stream) : launch<4, 2>(p, grid, stream));
     if (e != hipSuccess) return (int)e;
     e = hipGetLastError();                 // launch-configuration errors only; no synchronisation (CMHSA.cu:450)
     return e == hipSuccess ? CMHSA_OK : (int)e;
