@@ -645,16 +645,23 @@ Plan choose_plan(int64_t bh, int nqb) {
         for (int c = forced_chain ? c_max : c_min; c <= c_max; ++c) {
             for (int table = 0; table <= 1; ++table) {
                 if (forced_table >= 0 && forced_table != table) continue;
+                const bool forced = forced_waves || forced_chain || forced_table >= 0;
+                // only single-round grids are compared: skip the others before the O(nqb) pricing
+                if (!table && !forced && bh * pack_plan(nqb, waves, c).wgs_per_bh > (int64_t)cus * (waves == 8 ? 1 : 2)) continue;
                 Plan pl;
                 if (table) { if (!table_plan(pl, nqb, waves, c, bh, cus)) continue; }
                 else analytic_plan(pl, nqb, waves, c, bh, cus);
-                if (!pl.single_round && !(forced_waves || forced_chain || forced_table >= 0)) continue;
+                if (!pl.single_round && !forced) continue;
                 // ties: keep the earlier candidate (8 waves before 4, small c before large, analytic before table)
                 if (!have || pl.cycles < best.cycles * 0.98) { best = pl; have = true; }
             }
         }
     }
-    if (!have) analytic_plan(best, nqb, 4, (nqb + 3) / 4, bh, cus);      // several rounds (or an impossible forced combination)
+    if (!have) {                                     // several rounds (or an impossible forced combination)
+        best.pp = pack_plan(nqb, 4);
+        best.use_table = false;
+        best.n_wgs = best.pp.wgs_per_bh;
+    }
     static const bool verbose = getenv("CMHSA_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "cmhsa plan: bh=%lld nqb=%d -> waves=%d chain=%d %s wgs/bh=%d est=%.0f cycles\n", (long long)bh, nqb,
@@ -663,7 +670,7 @@ Plan choose_plan(int64_t bh, int nqb) {
 }
 
 // choose_plan() prices dozens of candidates; calls repeat the same few shapes, so the result is memoised
-const Plan &cached_plan(int64_t bh, int nqb) {
+Plan cached_plan(int64_t bh, int nqb) {
     struct Entry { int64_t bh; int nqb; Plan plan; };
     static std::mutex mu;
     static std::vector<Entry> cache;
@@ -671,9 +678,8 @@ const Plan &cached_plan(int64_t bh, int nqb) {
     for (const Entry &e : cache)
         if (e.bh == bh && e.nqb == nqb) return e.plan;
     if (cache.size() >= 256) cache.clear();
-    cache.reserve(256);                              // references handed out stay valid until the next clear
     cache.push_back(Entry{bh, nqb, choose_plan(bh, nqb)});
-    return cache.back().plan;
+    return cache.back().plan;                        // by value: the entry may be gone once the lock is released
 }
 
 }  // namespace
@@ -731,7 +737,7 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     const int64_t max_rs = q_row_stride > k_row_stride ? q_row_stride : k_row_stride;
     if ((max_rs > v_row_stride ? max_rs : v_row_stride) > (1LL << 24)) return CMHSA_ERR_TOO_LARGE;
 
-    const Plan plan = cached_plan(bh, (int)nqb);          // copied: the cache may be cleared by another thread
+    const Plan plan = cached_plan(bh, (int)nqb);
     const PackPlan &pl = plan.pp;
     const int waves = pl.waves;
     // grid = (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8

@@ -287,3 +287,41 @@ def test_long_sequences_spot_rows_against_f64(gpu_device, T, H):
     ones = torch.full_like(v, 0.75)
     const = cmhsa.attention_fwd(q, k, ones, H)
     assert (const - 0.75).abs().max().item() <= 5e-6 * 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"CMHSA_TABLE": "1", "CMHSA_WAVES": "8"}, {"CMHSA_TABLE": "1", "CMHSA_WAVES": "4"},
+                                 {"CMHSA_TABLE": "1", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "9"},
+                                 {"CMHSA_TABLE": "0", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "7"}])
+def test_forced_plans_in_a_child_process(env):
+    """The plan (workgroup shape, chain cap, analytic or table packing with up to four query blocks per workgroup) is
+    chosen per shape by a cost model; the environment overrides are read once per process, so each forced combination
+    runs in a child: ragged and exact lengths, one to many heads, against the f64 oracle at 1e-4."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%r, %r]
+import cmhsa
+from oracle import naive_attention as oracle
+rng = np.random.default_rng(77)
+worst = 0.0
+for B, T, H in ((1, 1, 1), (1, 31, 2), (1, 33, 3), (2, 257, 4), (1, 1000, 5), (1, 1024, 20), (3, 700, 12), (1, 2049, 2), (1, 8100, 1)):
+    qkv = rng.standard_normal((B, T, 3 * 64 * H), dtype=np.float32)
+    t = torch.from_numpy(qkv).cuda()
+    d = 64 * H
+    out = cmhsa.attention_fwd(t[..., :d], t[..., d:2 * d], t[..., 2 * d:], H).cpu().numpy()
+    for b in range(B):
+        for h in sorted({0, H - 1}):
+            sl = slice(64 * h, 64 * h + 64)
+            want = oracle.naive_attention_f64(qkv[b, :, sl], qkv[b, :, d + 64 * h:d + 64 * h + 64], qkv[b, :, 2 * d + 64 * h:2 * d + 64 * h + 64], 1)
+            worst = max(worst, float(np.abs(out[b, :, sl] - want).max()))
+print("WORST", worst)
+assert worst <= 1e-4
+""" % (root, os.path.join(root, "llm-inference_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "WORST" in r.stdout
