@@ -153,6 +153,30 @@ def main() -> None:
     want = oracle.naive_attention_f64(Q[B - 1, :, sl].cpu().numpy(), K[B - 1, :, sl].cpu().numpy(), V[B - 1, :, sl].cpu().numpy(), 1)
     max_err = float(abs(out[B - 1, :, sl].cpu().numpy() - want).max())
 
+    breakdown = None
+    if gathered is not None:
+        # compute-only rate per GPU and the all-gather on its own (outside the timed region)
+        def span(fn, reps=5):
+            fn()
+            fence()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(reps):
+                fn()
+            b.record(stream)
+            fence()
+            return a.elapsed_time(b) / reps
+        comp_ms = span(lambda: fwd(*call_args))
+        ag_ms = span(lambda: dist.all_gather_into_tensor(gathered, out))
+        t2 = torch.tensor([comp_ms, ag_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        comp_ms, ag_ms = float(t2[0]), float(t2[1])
+        recv_bytes = (world - 1) * out.numel() * 4
+        breakdown = {"compute_only_ms": round(comp_ms, 4),
+                     "compute_only_tflops_per_gpu": round(cmhsa.algorithmic_flops(B, T, H, 64) / (comp_ms * 1e-3) / 1e12, 2),
+                     "all_gather_ms": round(ag_ms, 4), "all_gather_received_bytes_per_rank": recv_bytes,
+                     "all_gather_GBps_received_per_rank": round(recv_bytes / (ag_ms * 1e-3) / 1e9, 1),
+                     "all_gather_GBps_per_xgmi_link": round(recv_bytes / (world - 1) / (ag_ms * 1e-3) / 1e9, 1)}
     if world > 1:
         tmax = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -198,6 +222,38 @@ def main() -> None:
             others[name] = {"workload": o["desc"], "us_per_launch": round(us, 2), "tflops": round(tf, 2),
                             "frac_of_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
             del x, oo
+        # SURVEY 8(d) config 2 asks for more than the headline: contiguous as well as QKV-sliced inputs, randn as well
+        # as rand, and the latency of ONE launch (launch -> completion seen by the host) next to the back-to-back rate
+        def timed(fn, reps):
+            for _ in range(5):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(reps):
+                fn()
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            return a.elapsed_time(b) * 1e3 / reps
+
+        variants = {}
+        for vname, maker, sliced in (("contiguous_rand", torch.rand, False), ("qkv_sliced_randn", torch.randn, True), ("contiguous_randn", torch.randn, False)):
+            if sliced:
+                x = maker((B, T, 3 * d), device=dev)
+                vq, vk, vv = x[..., :d], x[..., d:2 * d], x[..., 2 * d:]
+            else:
+                vq, vk, vv = (maker((B, T, d), device=dev) for _ in range(3))
+            va = (vq.data_ptr(), vk.data_ptr(), vv.data_ptr(), out.data_ptr(), vq.stride(1), vk.stride(1), vv.stride(1), out.stride(1),
+                  vq.stride(0), vk.stride(0), vv.stride(0), out.stride(0), B, T, H, 64, ctypes.c_void_p(stream.cuda_stream))
+            variants[vname + "_us"] = round(timed(lambda: fwd(*va), 200), 3)
+        lat = []
+        for _ in range(50):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            fwd(*call_args)
+            torch.cuda.synchronize(dev)
+            lat.append((time.perf_counter() - t1) * 1e6)
+        variants["single_launch_host_latency_us_median"] = round(statistics.median(lat), 2)
+        others["config2_variants"] = variants
         # the fused tanh-GELU kernel: HBM-bound, 8 algorithmic bytes per element
         for name, n in (("gelu_gpt2xl_b64_t512", 64 * 512 * 6400), ("gelu_gpt2_t256", 256 * 3072)):
             gx = torch.randn(n, device=dev)
@@ -270,6 +326,8 @@ def main() -> None:
     }
     if others:
         result["other_workloads"] = others
+    if breakdown:
+        result["config5_breakdown"] = breakdown
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(wl)
     if world > 1:
