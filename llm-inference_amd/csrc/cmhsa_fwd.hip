@@ -7,10 +7,10 @@
 // Decomposition (see DESIGN.md section 3 for the why and the measurements):
 //   * work item = one 32-row query block of one (batch, head); its KV range [0, q_block_end) is cut into
 //     32-key units (causal early exit: nothing past the diagonal is touched, only the diagonal unit is masked);
-//   * a workgroup has W = 8 (one per CU) or 4 (two per CU) wave64s and holds ONE long query block or a PAIR
-//     of a long and a short one (pack_plan(): every wave gets at most c units); the waves of a
-//     block split its units round-robin (split-KV inside the workgroup), so even B=1, T=1024 fills the chip
-//     with one round of equally long workgroups;
+//   * a workgroup has W = 8 (one per CU) or 4 (two per CU) wave64s and holds ONE long query block, a PAIR of
+//     a long and a short one (analytic plan, pack_plan()) or up to FOUR blocks listed in a table (choose_plan());
+//     a block with n units gets ceil(n/c) waves, which split its units round-robin (split-KV inside the
+//     workgroup), so even B=1, T=1024 fills the chip with one round of equally long workgroups;
 //   * S^T = K Q^T and O^T = V^T P^T on v_mfma_f32_32x32x2_f32: with S^T the query sits on the lane, so
 //     softmax statistics are per-lane scalars and the S^T accumulator registers are, as they stand, the B
 //     operand of the PV product (no LDS round trip, no lane shuffles);
@@ -49,8 +49,8 @@ constexpr int kHeadDim = 64;            // CMHSA.cu:432
 constexpr int kQBlock = 32;             // query rows per workgroup (one MFMA N-tile)
 constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
 // split-KV ways inside a workgroup = waves per workgroup (template parameter kWaves):
-//   8 -> one 128-KiB workgroup per CU (two of its waves per SIMD): shortest chain per query block
-//   4 -> two 64-KiB workgroups per CU: prologue/merge of one overlaps the main loop of the other
+//   8 -> one workgroup per CU (two of its waves per SIMD; 224 VGPRs allow no more): shortest chain per query block
+//   4 -> two workgroups per CU: prologue/merge of one overlaps the main loop of the other
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
 constexpr int kMaxSeg = 4;                                // query blocks ("segments") one workgroup can hold (template kSegs: 2 or 4)
 constexpr int kMaxTableWgs = 64;                          // workgroups per (b,h) an explicit segment table can describe
