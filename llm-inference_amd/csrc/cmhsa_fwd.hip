@@ -60,7 +60,7 @@ constexpr int lds_floats_q(int waves) { return waves * kUnitFloats; }
 constexpr int lds_floats_ml(int waves, int segs) { return (waves + segs) * kUnitFloats; }
 constexpr int lds_bytes(int waves, int segs) { return (lds_floats_ml(waves, segs) + waves * 64) * 4; }   // <= 98 KiB (8 waves), 65 KiB (4)
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
-constexpr float kRescaleThreshold = 16.f;                 // lazy rescale: keep the old max while it is within 2^16
+constexpr float kRescaleSum = 1.8446744e19f;              // 2^64: a row sum of P above it triggers the rescale path
 
 // Diagnostic build only (-DCMHSA_STAMPS, tools/Makefile target cmhsa_bench_stamps): s_memtime stamps of
 // one workgroup's phases go to a buffer of their own; no output value depends on them.  The shipped
@@ -361,15 +361,35 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             }
 
             // ---- online softmax, log2 domain; every processed unit has >=1 unmasked key per row.
-            //      Lazy rescale: O and l are only rescaled when some row's max grew by more than
-            //      2^kRescaleThreshold (fp32 has the exponent range; precision is unaffected). ----
-            float mx = s[0];
+            //      Speculative: P = exp2(S - m_run) is computed against the OLD running max without looking at the
+            //      unit's own max (16 max + a lane swap saved per unit; VALU work is paid in full beside fp32 MFMAs).
+            //      fp32 has the exponent range: as long as no row sum exceeds kRescaleSum = 2^64 nothing can
+            //      overflow later (<= 2^64 * 32 keys * units * |V|), and a stale max costs no precision (floating point
+            //      is scale-free).  Only if some row's sum is above the threshold -- or not finite: always on a
+            //      wave's first unit, where m_run = -inf -- the max is computed, O and l are rescaled and P is redone.
+            f32x16 pv;
+            f32x2 psum2 = {0.f, 0.f};                 // packed fp32 ops: two elements per VALU issue slot
+            if constexpr (!kFirst) {                  // (the first unit goes straight to the max path below)
+                const f32x2 m2 = {m_run, m_run};
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = xhalf_max(mx);
-            if (!__all(mx <= m_run + kRescaleThreshold)) {       // always taken on the first unit (m_run = -inf)
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 t = {s[r], s[r + 1]};
+                    t -= m2;
+                    t[0] = __builtin_amdgcn_exp2f(t[0]);
+                    t[1] = __builtin_amdgcn_exp2f(t[1]);
+                    psum2 += t;
+                    pv[r] = t[0];
+                    pv[r + 1] = t[1];
+                }
+            }
+            float psum = psum2[0] + psum2[1];
+            if (kFirst || !__all(psum < kRescaleSum)) {          // NaN and inf compare false: they take this path too
+                float mx = s[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                mx = xhalf_max(mx);
                 const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 on the first unit (m_run = -inf)
                 l_run *= alpha;
                 m_run = m_new;
 #pragma unroll
@@ -377,20 +397,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                     o0[r] *= alpha;
                     o1[r] *= alpha;
                 }
-            }
-            f32x2 psum2 = {0.f, 0.f};                 // packed fp32 ops: two elements per VALU issue slot
-            const f32x2 m2 = {m_run, m_run};
+                psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2 t = {s[r], s[r + 1]};
-                t -= m2;
-                t[0] = __builtin_amdgcn_exp2f(t[0]);
-                t[1] = __builtin_amdgcn_exp2f(t[1]);
-                psum2 += t;
-                s[r] = t[0];
-                s[r + 1] = t[1];
+                for (int r = 0; r < 16; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+                    psum += pv[r];
+                }
             }
-            l_run += psum2[0] + psum2[1];
+            l_run += psum;
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 2);
 #endif
@@ -422,8 +436,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                     __builtin_amdgcn_wave_barrier();
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r][0], s[r], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r][1], s[r], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r][0], pv[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[r][1], pv[r], o1, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // V(u+1), k-step r: its operand registers are free as soon as the two MFMAs above have issued;
                 // the load has the whole next QK chain + softmax to land

@@ -145,6 +145,29 @@ def test_online_softmax_rescale_is_forced(gpu_device):
     assert np.abs(out - oracle.naive_attention_f64(4 * q, 4 * k, v, H)).max() <= TOL
 
 
+@pytest.mark.parametrize("slope", [0.6, -0.6, 0.03, 3.0])
+def test_speculative_softmax_ramps(gpu_device, slope):
+    """The kernel computes P against the OLD running max and only looks at a unit's own max when a row sum leaves
+    [.., 2^64) (or is not finite).  Scores that ramp with the key index exercise both sides of that test: a rising ramp
+    makes the sums cross the threshold every few units (slope 0.6: ~2^28 per 32-key unit; slope 3: every unit
+    overflows to inf), a falling ramp leaves the max stale-high for the whole row (tiny but exact weights), a slow ramp
+    stays speculative throughout.  Scores of several hundred carry an absolute fp32 rounding error of ~1e-5 in the dot
+    product itself, which ANY fp32 evaluation turns into output error; so the bound is 1e-4 or three times the error
+    of the reference formula evaluated in fp32 (the torch oracle), whichever is larger."""
+    rng = np.random.default_rng(12)
+    T, H = 600, 2
+    d = 64 * H
+    q = np.ones((T, d), dtype=np.float32) + 0.01 * rng.standard_normal((T, d), dtype=np.float32)
+    k = rng.standard_normal((T, d), dtype=np.float32) * 0.05
+    k += (slope * 8.0 / 64.0) * np.arange(T, dtype=np.float32)[:, None] / np.float32(1.0)      # q.k/8 ~ slope * key index
+    v = rng.standard_normal((T, d), dtype=np.float32)
+    out = cmhsa.attention_fwd(*_dev((q, k, v), gpu_device), H).cpu().numpy()
+    assert np.isfinite(out).all()
+    want = oracle.naive_attention_f64(q, k, v, H)
+    ref32 = oracle.naive_attention_torch(torch.from_numpy(q)[None], torch.from_numpy(k)[None], torch.from_numpy(v)[None], H)[0].numpy()
+    assert np.abs(out - want).max() <= max(TOL, 3 * np.abs(ref32 - want).max())
+
+
 def test_every_output_element_is_written(gpu_device):
     # the torch binding hands the kernel torch::empty memory (CMHSA.cu:498): poison it first
     torch.manual_seed(3)
