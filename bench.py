@@ -147,6 +147,7 @@ def main() -> None:
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
 
+    clock_mhz = cmhsa.sustained_shader_clock_mhz(dev)       # outside the timed region; SURVEY 8(d): print the clock
     # parity spot-check outside the timed region: one (batch, head) against the f64 oracle
     from oracle import naive_attention as oracle
     sl = slice(64 * (H - 1), 64 * H)
@@ -322,6 +323,8 @@ def main() -> None:
                      "timing": "HIP events on the launch stream around the timed steps (includes inter-launch gaps)"},
         "percent_of_fp32_mfma_peak": round(100 * achieved / FP32_MFMA_PEAK_TFLOPS, 2),
         "max_abs_err_vs_f64_oracle": max_err,
+        "peak_assumes_clock_mhz": 2400,
+        "sustained_shader_clock_mhz_under_fp32_mfma_load": round(clock_mhz, 0),
         "device": torch.cuda.get_device_name(dev),
     }
     if others:

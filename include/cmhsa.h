@@ -106,6 +106,13 @@ int cmhsa_fp32_decode_step(const float *qkv_new, int64_t qkv_row_stride,
  * 4 * batch * d_model * (2*num_keys + 6)  (every K and V row once, q/k/v in, the appended rows and o out). */
 double cmhsa_decode_algorithmic_bytes(int batch, int num_keys, int num_heads, int head_dim);
 
+/* Measurement aid (no counterpart in the reference): runs fp32 MFMA chains on every CU for `iters` x 64 MFMAs per
+ * wave and stores, from one wave, { s_memtime at start, at end, s_memrealtime at start, at end } into out4_dev
+ * (4 x uint64, DEVICE memory supplied by the caller).  s_memtime ticks are shader-clock cycles, s_memrealtime runs
+ * at 100 MHz, so (t1 - t0) / (r1 - r0) * 100 MHz is the shader clock the chip SUSTAINS under matrix load -- the
+ * clock every "% of peak" figure silently assumes (bench.py prints it next to the 2.4 GHz of the peak constant). */
+int cmhsa_probe_shader_clock(unsigned long long *out4_dev, int iters, void *stream);
+
 /* Algorithmic work of one call, the figure every TFLOP/s number in this repo uses
  * (SURVEY.md section 8(d)):  F = 2 * batch * num_heads * head_dim * T * (T+1). */
 double cmhsa_algorithmic_flops(int batch, int seq_len, int num_heads, int head_dim);

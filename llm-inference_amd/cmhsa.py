@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "cmhsa_fp32_decode_step",
     "cmhsa_decode_algorithmic_bytes",
     "cmhsa_algorithmic_flops",
+    "cmhsa_probe_shader_clock",
     "gpt2_gelu_tanh_f32_fwd",        # include/gpt2_gelu.h
     "gpt2_gelu_algorithmic_bytes",
 )
@@ -74,6 +75,8 @@ def load_library() -> ctypes.CDLL:
     lib.cmhsa_fp32_decode_step.argtypes = [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, vp]
     lib.cmhsa_decode_algorithmic_bytes.restype = ctypes.c_double
     lib.cmhsa_decode_algorithmic_bytes.argtypes = [i32, i32, i32, i32]
+    lib.cmhsa_probe_shader_clock.restype = i32
+    lib.cmhsa_probe_shader_clock.argtypes = [vp, i32, vp]
     lib.cmhsa_algorithmic_flops.restype = ctypes.c_double
     lib.cmhsa_algorithmic_flops.argtypes = [i32, i32, i32, i32]
     lib.gpt2_gelu_tanh_f32_fwd.restype = i32
@@ -188,6 +191,21 @@ def decode_step(qkv_new: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     if rc != CMHSA_OK:
         raise CmhsaError(rc, status_string(rc))
     return out
+
+
+def sustained_shader_clock_mhz(device=None, iters: int = 2000) -> float:
+    """Shader clock (MHz) the chip sustains while every CU runs fp32 MFMA chains: cmhsa_probe_shader_clock."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.zeros(4, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        for _ in range(2):                                   # the first pass ramps the clocks, the second is read
+            rc = load_library().cmhsa_probe_shader_clock(out.data_ptr(), iters, ctypes.c_void_p(stream))
+            if rc != CMHSA_OK:
+                raise CmhsaError(rc, status_string(rc))
+        torch.cuda.synchronize(device)
+    t0, t1, r0, r1 = (int(x) for x in out.tolist())
+    return (t1 - t0) / max(r1 - r0, 1) * 100.0
 
 
 def gelu_tanh_fwd(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
