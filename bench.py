@@ -90,19 +90,25 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP attention path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (never for reported numbers):
+    # CMHSA_BENCH_BACKEND=gloo lets several ranks share a card (RCCL refuses two ranks on one device)
+    backend = os.environ.get("CMHSA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import cmhsa
 
     lib = cmhsa.load_library()
     wl = WORKLOADS[args.workload]
     B, H, T = wl["B"], wl["H"], wl["T"]
+    if backend != "nccl":
+        B, T = min(B, 2), min(T, 1024)                   # rehearsal only: keep the host-staged collective small
     sharded = bool(wl.get("head_sharded"))
     if sharded:
         if H % world != 0:
@@ -327,6 +333,8 @@ def main() -> None:
         "sustained_shader_clock_mhz_under_fp32_mfma_load": round(clock_mhz, 0),
         "device": torch.cuda.get_device_name(dev),
     }
+    if backend != "nccl":
+        result["data"] += f"; REHEARSAL with backend {backend}: ranks may share a GPU, numbers are not measurements"
     if others:
         result["other_workloads"] = others
     if breakdown:
