@@ -1,13 +1,17 @@
-"""ctypes view of the C ABI in include/cmhsa.h (libcmhsa_hip.so).
+"""ctypes view of the C ABI in include/cmhsa.h and include/gpt2_gelu.h (libcmhsa_hip.so).
 
 This is the host-side plumbing only: device memory and streams come from PyTorch-ROCm, the
 arithmetic is entirely in the hand-written gfx950 kernels.  There is NO fallback: if the library
 is missing or no GPU is present, the calls raise.
 
-The torch op `torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_torch`
-(registered by importing the sibling extension module `causal_multihead_self_attention`, as the
-reference does at causal_self_attention.py:60-63) goes through the same entry point,
-`cmhsa_fp32_fwd`; tests call both.
+  attention_fwd / attention_fwd_raw      cmhsa_fp32_fwd            full-sequence causal attention (the hot path)
+  attention_fwd_packed_qkv               cmhsa_fp32_fwd_packed_qkv the same over one packed (.., T, 3*d_model) buffer
+  decode_step                            cmhsa_fp32_decode_step    one-token step over a KV cache (opt-in)
+  gelu_tanh_fwd                          gpt2_gelu_tanh_f32_fwd    fused tanh-GELU
+  sustained_shader_clock_mhz             cmhsa_probe_shader_clock  measurement aid
+
+The torch ops of the sibling extension module `causal_multihead_self_attention` (importing it registers them,
+as the reference does at causal_self_attention.py:60-63) go through the same entry points; tests call both.
 """
 from __future__ import annotations
 
