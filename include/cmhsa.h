@@ -25,7 +25,7 @@ extern "C" {
  * (std::invalid_argument): nothing here throws or exits. */
 #define CMHSA_OK                 0
 #define CMHSA_ERR_NULL_POINTER  -1   /* a tensor pointer is NULL while its size is non-zero        */
-#define CMHSA_ERR_BAD_SHAPE     -2   /* batch/seq_len/num_heads negative or num_heads == 0         */
+#define CMHSA_ERR_BAD_SHAPE     -2   /* batch/seq_len/num_heads negative, num_heads == 0, negative stride */
 #define CMHSA_ERR_HEAD_DIM      -3   /* head_dim != 64          (CMHSA.cu:432 "Head dimension must be 64") */
 #define CMHSA_ERR_ALIGNMENT     -4   /* pointer not 16-B aligned or stride % 4 != 0 (CMHSA.cu:480-486)     */
 #define CMHSA_ERR_TOO_LARGE     -5   /* grid or 32-bit tile index would overflow                   */

@@ -776,6 +776,7 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     const int64_t stride_bits = q_row_stride | k_row_stride | v_row_stride | o_row_stride |
                                 q_batch_stride | k_batch_stride | v_batch_stride | o_batch_stride;
     if ((ptr_bits & 15) || (stride_bits & 3)) return CMHSA_ERR_ALIGNMENT;
+    if (stride_bits < 0) return CMHSA_ERR_BAD_SHAPE;             // a negative stride (sign bit set in the OR of all)
 
     const int64_t nqb = ((int64_t)seq_len + kQBlock - 1) / kQBlock;
     const int64_t bh = (int64_t)batch * num_heads;

@@ -70,6 +70,7 @@ def test_argument_validation_needs_no_gpu():
     assert call(q=null) == cmhsa.CMHSA_ERR_NULL_POINTER
     assert call(k=bad_align) == cmhsa.CMHSA_ERR_ALIGNMENT
     assert call(rs=(64, 66, 64, 64)) == cmhsa.CMHSA_ERR_ALIGNMENT
+    assert call(rs=(64, -64, 64, 64)) == cmhsa.CMHSA_ERR_BAD_SHAPE          # negative strides are not supported
     assert call(T=0) == cmhsa.CMHSA_OK          # empty sequence: successful no-op
     assert call(B=0) == cmhsa.CMHSA_OK
     assert lib.cmhsa_fp32_fwd_2d(good, good, good, good, 100, 100, 100, 100, 8, 100, 3, null) == cmhsa.CMHSA_ERR_BAD_SHAPE
