@@ -725,7 +725,7 @@ int cmhsa_probe_shader_clock(unsigned long long *out4_dev, int iters, void *stre
     if (!out4_dev) return CMHSA_ERR_NULL_POINTER;
     if (iters <= 0 || ((uintptr_t)out4_dev & 7)) return CMHSA_ERR_BAD_SHAPE;
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)(cus > 0 ? cus : 256) * 2), dim3(256), 0, static_cast<hipStream_t>(stream),
                        out4_dev, iters, 1.0f);
     const hipError_t e = hipGetLastError();
