@@ -367,6 +367,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             //      overflow later (<= 2^64 * 32 keys * units * |V|), and a stale max costs no precision (floating point
             //      is scale-free).  Only if some row's sum is above the threshold -- or not finite: always on a
             //      wave's first unit, where m_run = -inf -- the max is computed, O and l are rescaled and P is redone.
+            // the two waves of a SIMD: the one in its softmax (VALU) phase yields to the one feeding the matrix pipe
+            // (s_setprio 0 here, 2 again below: measured -1.5 % on BASELINE config 2, neutral on long grids)
+            __builtin_amdgcn_s_setprio(0);
             f32x16 pv;
             f32x2 psum2 = {0.f, 0.f};                 // packed fp32 ops: two elements per VALU issue slot
             if constexpr (!kFirst) {                  // (the first unit goes straight to the max path below)
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 }
             }
             l_run += psum;
+            __builtin_amdgcn_s_setprio(2);
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 2);
 #endif
