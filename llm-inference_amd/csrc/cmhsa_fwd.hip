@@ -369,7 +369,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             //      wave's first unit, where m_run = -inf -- the max is computed, O and l are rescaled and P is redone.
             // the two waves of a SIMD: the one in its softmax (VALU) phase yields to the one feeding the matrix pipe
             // (s_setprio 0 here, 2 again below: measured -1.5 % on BASELINE config 2, neutral on long grids)
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (!kFirst) __builtin_amdgcn_s_setprio(0);    // (the first unit, which every wave reaches together, stays high: measured)
+            __builtin_amdgcn_sched_barrier(0);           // (s_setprio is no scheduling barrier of its own)
             f32x16 pv;
             f32x2 psum2 = {0.f, 0.f};                 // packed fp32 ops: two elements per VALU issue slot
             if constexpr (!kFirst) {                  // (the first unit goes straight to the max path below)
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 }
             }
             l_run += psum;
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(2);
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 2);
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 #endif
         };
 
+        __builtin_amdgcn_s_setprio(2);
         unit(wloc, std::true_type{});            // every active wave owns at least one unit (wloc < seg_waves <= n_units)
         for (int u = wloc + seg_waves; u < n_units; u += seg_waves) unit(u, std::false_type{});
         l_run = xhalf_sum(l_run);
