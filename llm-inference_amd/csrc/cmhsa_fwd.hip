@@ -139,7 +139,7 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t unit_rsrc(const float *head_base, int64_t rs, int row0, int n_rows,
                                                             bool enable = true) {
     const int valid = min(kKeyUnit, n_rows - row0);       // >= 1 for every unit the kernel touches
-    const int bytes = enable ? ((valid - 1) * (int)rs + kHeadDim) * 4 : 0;
+    const int bytes = (((valid - 1) * (int)rs + kHeadDim) * 4) & -(int)enable;     // mask, not select: no scalar branch
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(head_base + (int64_t)row0 * rs), 0, bytes, 0x00020000);
 }
 
