@@ -488,39 +488,45 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     STAMP(120);
     {
         float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
-        for (int item = wave; item < 8 * n_seg; item += kWaves) {            // wave-uniform trip count
-            const int sg = item >> 3, pi = item & 7;
-            int w_lo = 0, w_hi = 0, n_sg = 1;
+        // Items (segment, pair) with item = 8 * segment + pair go round-robin over the waves, so a wave's items share
+        // their pair index (8 waves: pair = wave; 4 waves: pair = wave and wave + 4): the image of every wave is read
+        // ONCE per pair and serves all segments -- each publishing wave belongs to exactly one of them.
 #pragma unroll
-            for (int i = 0; i < kSegs; ++i)
-                if (i == sg) { w_lo = seg_lo[i]; w_hi = seg_hi[i]; n_sg = seg_n[i]; }
-            // wave-uniform bit masks instead of selects keep the LDS reads unconditional and back to back
-            // (hipcc turns a uniform select of a load into a branch with a full lgkmcnt(0) wait per read)
-            float mw[kWaves], lw[kWaves];
-            f32x4 ow[kWaves];
-            float m_tot = -INFINITY;
+        for (int pc = 0; pc < 8 / kWaves; ++pc) {
+            const int pi = wave + pc * kWaves;
+            float mv[kWaves], lv[kWaves];
+            u32x4 ov[kWaves];
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) {
-                const unsigned mine = (w >= w_lo && w < w_hi) ? 0xffffffffu : 0u;
-                const float mv = ml_all[w * 64 + l31], lv = ml_all[w * 64 + 32 + l31];
-                const u32x4 ov = *reinterpret_cast<const u32x4 *>(lds + w * kUnitFloats + (pi * 64 + lane) * 4);
-                mw[w] = __uint_as_float((__float_as_uint(mv) & mine) | (~mine & 0xff800000u));   // -inf when not mine
-                lw[w] = __uint_as_float(__float_as_uint(lv) & mine);
-                ow[w] = __builtin_bit_cast(f32x4, ov & mine);
-                m_tot = fmaxf(m_tot, mw[w]);
+                mv[w] = ml_all[w * 64 + l31];
+                lv[w] = ml_all[w * 64 + 32 + l31];
+                ov[w] = *reinterpret_cast<const u32x4 *>(lds + w * kUnitFloats + (pi * 64 + lane) * 4);
             }
-            float l_tot = 0.f;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-                const float f = __builtin_amdgcn_exp2f(mw[w] - m_tot);
-                l_tot += lw[w] * f;
-                acc += ow[w] * f;
-            }
-            acc *= 1.0f / l_tot;
-            const int row = (n_sg - 1) * kQBlock + l31;
             const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);       // = 2 * (acc_row(2 pi) + 4 half)
-            if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
+#pragma unroll
+            for (int sg = 0; sg < kSegs; ++sg) {
+                if (sg >= n_seg) break;                                          // wave-uniform
+                // wave-uniform bit masks, not selects or branches, pick the segment's waves
+                float mw[kWaves];
+                float m_tot = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) {
+                    const unsigned mine = (w >= seg_lo[sg] && w < seg_hi[sg]) ? 0xffffffffu : 0u;
+                    mw[w] = __uint_as_float((__float_as_uint(mv[w]) & mine) | (~mine & 0xff800000u));   // -inf when not mine
+                    m_tot = fmaxf(m_tot, mw[w]);
+                }
+                float l_tot = 0.f;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) {
+                    const float f = __builtin_amdgcn_exp2f(mw[w] - m_tot);      // 0 for the other segments' waves
+                    l_tot += lv[w] * f;
+                    acc += __builtin_bit_cast(f32x4, ov[w]) * f;
+                }
+                acc *= 1.0f / l_tot;
+                const int row = (seg_n[sg] - 1) * kQBlock + l31;
+                if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
+            }
         }
     }
 #ifdef CMHSA_STAMPS
