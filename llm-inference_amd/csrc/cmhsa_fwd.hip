@@ -55,7 +55,7 @@ constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
 constexpr int kMaxSeg = 4;                                // query blocks ("segments") one workgroup can hold (template kSegs: 2 or 4)
 constexpr int kMaxTableWgs = 64;                          // workgroups per (b,h) an explicit segment table can describe
 // LDS: [kWaves][8 KiB] each wave's K unit (later its merge image) | [kSegs][8 KiB] pre-scaled query blocks |
-//      [kWaves][m[32] | l[32]] softmax statistics for the merge
+//      [kWaves][32 x (m, l)] softmax statistics for the merge
 constexpr int lds_floats_q(int waves) { return waves * kUnitFloats; }
 constexpr int lds_floats_ml(int waves, int segs) { return (waves + segs) * kUnitFloats; }
 constexpr int lds_bytes(int waves, int segs) { return (lds_floats_ml(waves, segs) + waves * 64) * 4; }   // <= 98 KiB (8 waves), 65 KiB (4)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     float *wlds = lds + wave * kUnitFloats;      // private to this wave: its current K unit (8 KiB); later its merge image
     float *qlds_all = lds + lds_floats_q(kWaves);                      // shared: the segments' query blocks,
     float *qlds = qlds_all + seg * kUnitFloats;                        // pre-scaled, K-style swizzle
-    float *ml_all = lds + lds_floats_ml(kWaves, kSegs);                       // [wave][m[32] | l[32]]
+    float *ml_all = lds + lds_floats_ml(kWaves, kSegs);                       // [wave][query][m, l]
 
     // per-lane byte offsets inside a unit
     const int sub = lane >> 4, chunk = lane & 15;
@@ -479,10 +479,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             const f32x4 t = {o0[2 * pi], o1[2 * pi], o0[2 * pi + 1], o1[2 * pi + 1]};
             pub[pi * 64 + lane] = t;
         }
-        if (lane < 32) {
-            ml_all[wave * 64 + lane] = m_run;
-            ml_all[wave * 64 + 32 + lane] = l_run;
-        }
+        if (lane < 32) *reinterpret_cast<f32x2 *>(ml_all + wave * 64 + 2 * lane) = f32x2{m_run, l_run};
     }
     __syncthreads();
     STAMP(120);
@@ -498,8 +495,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             u32x4 ov[kWaves];
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) {
-                mv[w] = ml_all[w * 64 + l31];
-                lv[w] = ml_all[w * 64 + 32 + l31];
+                const f32x2 ml = *reinterpret_cast<const f32x2 *>(ml_all + w * 64 + 2 * l31);
+                mv[w] = ml[0];
+                lv[w] = ml[1];
                 ov[w] = *reinterpret_cast<const u32x4 *>(lds + w * kUnitFloats + (pi * 64 + lane) * 4);
             }
             const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);       // = 2 * (acc_row(2 pi) + 4 half)
