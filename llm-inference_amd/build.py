@@ -5,6 +5,10 @@
 Produces (all git-ignored, all shipped to the GPU box by gpurun):
   llm-inference_amd/lib/libcmhsa_hip.so                       hand-written gfx950 kernels + C ABI (attention, GELU)
   llm-inference_amd/causal_multihead_self_attention.<abi>.so  torch binding / importable module
+  tests/helpers/libcmhsa_hip_planenv.so                       TEST build of the same kernels with -DCMHSA_PLAN_ENV: reads
+                                                              CMHSA_WAVES/CHAIN/TABLE/VERBOSE to force a plan (the shipped
+                                                              library reads no environment variable)
+  tests/helpers/libcmhsa_testhelpers.so                       test helper kernels (LDS poisoning)
 
 The reference builds its extension with torch.utils.cpp_extension.CUDAExtension
 (reference torch_extensions/causal_multihead_self_attention/setup.py:4-12); here the kernel
@@ -27,6 +31,9 @@ ROCM = os.environ.get("ROCM_HOME", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 KERNEL_LIB = os.path.join(LIBDIR, "libcmhsa_hip.so")
+TEST_HELPERS = os.path.join(ROOT, "tests", "helpers")
+PLANENV_LIB = os.path.join(TEST_HELPERS, "libcmhsa_hip_planenv.so")
+TESTHELPER_LIB = os.path.join(TEST_HELPERS, "libcmhsa_testhelpers.so")
 EXT_NAME = "causal_multihead_self_attention"
 EXT_PATH = os.path.join(HERE, EXT_NAME + sysconfig.get_config_var("EXT_SUFFIX"))
 
@@ -43,14 +50,30 @@ def _run(cmd: list[str]) -> None:
     subprocess.run(cmd, check=True)
 
 
-def build_kernel_lib(force: bool = False) -> str:
+def _kernel_sources() -> tuple[list[str], list[str]]:
     hip = [os.path.join(CSRC, "cmhsa_fwd.hip"), os.path.join(CSRC, "cmhsa_decode.hip"), os.path.join(CSRC, "gelu_fwd.hip")]
     headers = [os.path.join(INCLUDE, "cmhsa.h"), os.path.join(INCLUDE, "gpt2_gelu.h")]
+    return hip, headers
+
+
+def build_kernel_lib(force: bool = False) -> str:
+    hip, headers = _kernel_sources()
     if force or _stale(KERNEL_LIB, hip + headers):
         os.makedirs(LIBDIR, exist_ok=True)
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
               "-I" + INCLUDE, "-o", KERNEL_LIB, *hip])
     return KERNEL_LIB
+
+
+def build_test_libs(force: bool = False) -> None:
+    """Test-only libraries (never loaded by the product package): the plan-forcing build and the helper kernels."""
+    hip, headers = _kernel_sources()
+    if force or _stale(PLANENV_LIB, hip + headers):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCMHSA_PLAN_ENV",
+              "-I" + INCLUDE, "-o", PLANENV_LIB, *hip])
+    helper_src = [os.path.join(TEST_HELPERS, "lds_poison.hip")]
+    if force or _stale(TESTHELPER_LIB, helper_src):
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", TESTHELPER_LIB, *helper_src])
 
 
 def build_torch_binding(force: bool = False) -> str:
@@ -74,6 +97,7 @@ def build_torch_binding(force: bool = False) -> str:
 def build_all(force: bool = False) -> None:
     build_kernel_lib(force)
     build_torch_binding(force)
+    build_test_libs(force)
 
 
 if __name__ == "__main__":

@@ -29,22 +29,12 @@ _EXTENSION_MODULE = "causal_multihead_self_attention"
 
 
 class ScaledDotProductAttentionBackend(Enum):
+    # Two members only.  The reference's PYTORCH_SDPA_* members (reference :8-11) select stock PyTorch kernels and its
+    # CUSTOM_CUDA_VERSION_1..12 members frozen CUDA snapshots: neither is part of this path, and this build has no
+    # multi-backend dispatch -- the custom kernel plus the naive formula it is checked against on the same device.
     NAIVE_PYTORCH = "NAIVE_PYTORCH"
     CUSTOM_CUDA = "CUSTOM_CUDA"
-    PYTORCH_SDPA_MATH = "PYTORCH_SDPA_MATH"
-    PYTORCH_SDPA_FLASH_ATTENTION = "PYTORCH_SDPA_FLASH_ATTENTION"
-    PYTORCH_SDPA_EFFICIENT_ATTENTION = "PYTORCH_SDPA_EFFICIENT_ATTENTION"
-    PYTORCH_SDPA_CUDNN_ATTENTION = "PYTORCH_SDPA_CUDNN_ATTENTION"
     CUSTOM_HIP = "CUSTOM_CUDA"      # alias of CUSTOM_CUDA (same value => same member)
-
-
-_SDPA_KERNELS = {
-    ScaledDotProductAttentionBackend.PYTORCH_SDPA_MATH: "MATH",
-    ScaledDotProductAttentionBackend.PYTORCH_SDPA_FLASH_ATTENTION: "FLASH_ATTENTION",
-    ScaledDotProductAttentionBackend.PYTORCH_SDPA_EFFICIENT_ATTENTION: "EFFICIENT_ATTENTION",
-    ScaledDotProductAttentionBackend.PYTORCH_SDPA_CUDNN_ATTENTION: "CUDNN_ATTENTION",
-}
-PYTORCH_SDPA_BACKENDS = list(_SDPA_KERNELS)
 
 
 def load_attention_backend(backend: ScaledDotProductAttentionBackend) -> None:
@@ -88,15 +78,6 @@ def _custom_attention(queries, keys, values, num_heads):
     return op(Q=queries, K=keys, V=values, num_heads=num_heads)
 
 
-def _torch_sdpa(kind: str, queries, keys, values, num_heads):
-    from torch.nn.attention import SDPBackend, sdpa_kernel
-
-    q, k, v = (_split_heads(t, num_heads) for t in (queries, keys, values))
-    with sdpa_kernel(getattr(SDPBackend, kind)):
-        ctx = torch.nn.functional.scaled_dot_product_attention(query=q, key=k, value=v, is_causal=True)
-    return _merge_heads(ctx)
-
-
 def scaled_dot_product_attention(backend: ScaledDotProductAttentionBackend,
                                  queries: torch.Tensor,
                                  keys: torch.Tensor,
@@ -111,8 +92,6 @@ def scaled_dot_product_attention(backend: ScaledDotProductAttentionBackend,
                                                           num_heads=num_heads, causal_mask=causal_mask)
     if backend is ScaledDotProductAttentionBackend.CUSTOM_CUDA:
         return _custom_attention(queries, keys, values, num_heads)
-    if backend in _SDPA_KERNELS:
-        return _torch_sdpa(_SDPA_KERNELS[backend], queries, keys, values, num_heads)
     raise ValueError("Backend not implemented yet")
 
 

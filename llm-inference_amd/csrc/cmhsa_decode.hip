@@ -144,8 +144,10 @@ int cmhsa_fp32_decode_step(const float *qkv_new, int64_t qkv_row_stride,
     p.qkv_new = qkv_new; p.k_cache = k_cache; p.v_cache = v_cache; p.o = o; p.pos = pos_dev;
     p.qkv_rs = qkv_row_stride; p.cache_rs = cache_row_stride; p.cache_bs = batch == 1 ? 0 : cache_batch_stride; p.o_rs = o_row_stride;
     p.capacity = capacity; p.num_heads = num_heads;
-    hipLaunchKernelGGL(cmhsa_decode_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream), p);
-    const hipError_t e = hipGetLastError();
+    // the launch's own status (hipGetLastError would also report, and clear, an unrelated earlier error of this thread)
+    void *args[] = {&p};
+    const hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(cmhsa_decode_kernel), dim3((unsigned)blocks), dim3(kThreads),
+                                         args, 0, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? CMHSA_OK : (int)e;
 }
 

@@ -479,8 +479,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             const f32x4 t = {o0[2 * pi], o1[2 * pi], o0[2 * pi + 1], o1[2 * pi + 1]};
             pub[pi * 64 + lane] = t;
         }
-        if (lane < 32) *reinterpret_cast<f32x2 *>(ml_all + wave * 64 + 2 * lane) = f32x2{m_run, l_run};
     }
+    // EVERY wave publishes its (m, l) -- an idle wave (no segment) its initial (-inf, 0): the merge reads all kWaves
+    // slots and multiplies l by a weight of 0 for waves outside the segment, so a slot must never hold leftover LDS
+    // bits of an earlier kernel (inf or NaN patterns: 0 * NaN would poison the whole row block).  The idle wave's O
+    // image is zero already: its K unit was stored from a zero-record descriptor in the prologue.
+    if (lane < 32) *reinterpret_cast<f32x2 *>(ml_all + wave * 64 + 2 * lane) = f32x2{m_run, l_run};
     __syncthreads();
     STAMP(120);
     {
@@ -547,9 +551,11 @@ hipError_t launch(const Params &p, dim3 grid, void *stream) {
         if (e != hipSuccess) return e;
         if (flag) flag->store(1, std::memory_order_release);
     }
-    void (*kernel)(Params) = cmhsa_fwd_kernel<kWaves, kSegs>;
-    hipLaunchKernelGGL(kernel, grid, dim3(kWaves * 64), lds_bytes(kWaves, kSegs), static_cast<hipStream_t>(stream), p);
-    return hipSuccess;
+    // hipLaunchKernel returns this launch's own status: an error left behind by an unrelated earlier HIP call on
+    // this thread is neither reported as ours nor cleared (hipGetLastError would do both)
+    void *args[] = {const_cast<Params *>(&p)};
+    return hipLaunchKernel(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs>), grid, dim3(kWaves * 64), args,
+                           lds_bytes(kWaves, kSegs), static_cast<hipStream_t>(stream));
 }
 
 // ---- plan selection (host) ---------------------------------------------------------------------------------------
@@ -563,7 +569,6 @@ hipError_t launch(const Params &p, dim3 grid, void *stream) {
 // wins; an 8-wave workgroup owns its CU (two of its waves per SIMD), two 4-wave workgroups share one.  Grids of
 // several rounds run within +-3 % of each other under every plan tried, so they keep the analytic plan with 4-wave
 // workgroups at the smallest c (two co-resident workgroups hide each other's prologue and merge).
-// Environment overrides for experiments (read once): CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1.
 struct Plan {
     PackPlan pp;
     bool use_table = false;
@@ -651,15 +656,29 @@ void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
     price(pl, blocks, pl.pp.wgs_per_bh, bh, cus);
 }
 
-Plan choose_plan(int64_t bh, int nqb) {
-    static const int forced_waves = [] { const char *e = getenv("CMHSA_WAVES"); return e ? atoi(e) : 0; }();
-    static const int forced_chain = [] { const char *e = getenv("CMHSA_CHAIN"); return e ? atoi(e) : 0; }();
-    static const int forced_table = [] { const char *e = getenv("CMHSA_TABLE"); return e ? atoi(e) : -1; }();
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
+// Experiments only (tools/ and the forced-plan tests build the library with -DCMHSA_PLAN_ENV): CMHSA_WAVES=4|8,
+// CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force a plan, CMHSA_VERBOSE prints the choice.  The shipped library reads no
+// environment variable.
+#ifdef CMHSA_PLAN_ENV
+int env_int(const char *name, int fallback) { const char *e = getenv(name); return e ? atoi(e) : fallback; }
+#else
+constexpr int env_int(const char *, int fallback) { return fallback; }
+#endif
+
+int device_cu_count(int dev) {
+    static std::atomic<int> cached[64];
+    const bool slot = dev >= 0 && dev < 64;
+    int n = slot ? cached[dev].load(std::memory_order_relaxed) : 0;
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (slot) cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+Plan choose_plan(int64_t bh, int nqb, int cus) {
+    static const int forced_waves = env_int("CMHSA_WAVES", 0);
+    static const int forced_chain = env_int("CMHSA_CHAIN", 0);
+    static const int forced_table = env_int("CMHSA_TABLE", -1);
     Plan best;
     bool have = false;
     for (int waves = 8; waves >= 4; waves -= 4) {
@@ -670,7 +689,7 @@ Plan choose_plan(int64_t bh, int nqb) {
         for (int c = forced_chain ? c_max : c_min; c <= c_max; ++c) {
             for (int table = 0; table <= 1; ++table) {
                 if (forced_table >= 0 && forced_table != table) continue;
-                const bool forced = forced_waves || forced_chain || forced_table >= 0;
+                const bool forced = (forced_waves != 0) | (forced_chain != 0) | (forced_table >= 0);
                 // only single-round grids are compared: skip the others before the O(nqb) pricing
                 if (!table && !forced && bh * pack_plan(nqb, waves, c).wgs_per_bh > (int64_t)cus * (waves == 8 ? 1 : 2)) continue;
                 Plan pl;
@@ -687,23 +706,24 @@ Plan choose_plan(int64_t bh, int nqb) {
         best.use_table = false;
         best.n_wgs = best.pp.wgs_per_bh;
     }
-    static const bool verbose = getenv("CMHSA_VERBOSE") != nullptr;
+    static const bool verbose = env_int("CMHSA_VERBOSE", 0) != 0;
     if (verbose)
-        fprintf(stderr, "cmhsa plan: bh=%lld nqb=%d -> waves=%d chain=%d %s wgs/bh=%d est=%.0f cycles\n", (long long)bh, nqb,
+        fprintf(stderr, "cmhsa plan: bh=%lld nqb=%d cus=%d -> waves=%d chain=%d %s wgs/bh=%d est=%.0f cycles\n", (long long)bh, nqb, cus,
                 best.pp.waves, best.pp.chain, best.use_table ? "table" : "analytic", best.n_wgs, best.cycles);
     return best;
 }
 
-// choose_plan() prices dozens of candidates; calls repeat the same few shapes, so the result is memoised
-Plan cached_plan(int64_t bh, int nqb) {
-    struct Entry { int64_t bh; int nqb; Plan plan; };
+// choose_plan() prices dozens of candidates; calls repeat the same few shapes, so the result is memoised per
+// (shape, CU count of the device the call runs on)
+Plan cached_plan(int64_t bh, int nqb, int cus) {
+    struct Entry { int64_t bh; int nqb, cus; Plan plan; };
     static std::mutex mu;
     static std::vector<Entry> cache;
     std::lock_guard<std::mutex> lock(mu);
     for (const Entry &e : cache)
-        if (e.bh == bh && e.nqb == nqb) return e.plan;
+        if (e.bh == bh && e.nqb == nqb && e.cus == cus) return e.plan;
     if (cache.size() >= 256) cache.clear();
-    cache.push_back(Entry{bh, nqb, choose_plan(bh, nqb)});
+    cache.push_back(Entry{bh, nqb, cus, choose_plan(bh, nqb, cus)});
     return cache.back().plan;                        // by value: the entry may be gone once the lock is released
 }
 
@@ -737,9 +757,10 @@ int cmhsa_probe_shader_clock(unsigned long long *out4_dev, int iters, void *stre
     if (iters <= 0 || ((uintptr_t)out4_dev & 7)) return CMHSA_ERR_BAD_SHAPE;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)(cus > 0 ? cus : 256) * 2), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       out4_dev, iters, 1.0f);
-    const hipError_t e = hipGetLastError();
+    float seed = 1.0f;
+    void *args[] = {&out4_dev, &iters, &seed};
+    const hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(clock_probe_kernel), dim3((unsigned)(cus > 0 ? cus : 256) * 2),
+                                         dim3(256), args, 0, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? CMHSA_OK : (int)e;
 }
 
@@ -791,12 +812,16 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
 
     const int64_t nqb = ((int64_t)seq_len + kQBlock - 1) / kQBlock;
     const int64_t bh = (int64_t)batch * num_heads;
-    if (nqb > 0x3fffffffLL || bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    // 32-bit row arithmetic in the kernel: the software pipeline forms row numbers up to (nqb + 2 * 8 waves) * 32 and
+    // multiplies none of them by a stride in 32 bits (row offsets are 64-bit), so the bound is on the row number itself
+    if ((nqb + 16) * kKeyUnit > 0x7fffffffLL || bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
     // 32-bit byte offsets inside a 32-row unit (buffer loads): 32 rows * row_stride * 4 B must fit
     const int64_t max_rs = q_row_stride > k_row_stride ? q_row_stride : k_row_stride;
     if ((max_rs > v_row_stride ? max_rs : v_row_stride) > (1LL << 24)) return CMHSA_ERR_TOO_LARGE;
 
-    const Plan plan = cached_plan(bh, (int)nqb);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    const Plan plan = cached_plan(bh, (int)nqb, device_cu_count(dev));
     const PackPlan &pl = plan.pp;
     const int waves = pl.waves;
     // grid = (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8
@@ -824,9 +849,7 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
 
     hipError_t e = p.use_table ? (waves == 8 ? launch<8, 4>(p, grid, stream) : launch<4, 4>(p, grid, stream))
                                : (waves == 8 ? launch<8, 2>(p, grid, stream) : launch<4, 2>(p, grid, stream));
-    if (e != hipSuccess) return (int)e;
-    e = hipGetLastError();                 // launch-configuration errors only; no synchronisation (CMHSA.cu:450)
-    return e == hipSuccess ? CMHSA_OK : (int)e;
+    return e == hipSuccess ? CMHSA_OK : (int)e;     // launch-configuration errors only; no synchronisation (CMHSA.cu:450)
 }
 
 int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,

@@ -82,18 +82,28 @@ int gpt2_gelu_tanh_f32_fwd(const float *x, float *y, int64_t n, void *stream) {
     // small activations (generation: T x 4*d_model, a few MB) are latency-bound: one float4 per lane spreads them
     // over every CU; large ones keep four loads in flight per lane
     const int unroll = n4 >= (1 << 20) ? 4 : 1;
+    // each launch's own status (hipGetLastError would also report, and clear, an unrelated earlier error of this thread)
     if (n4 > 0) {
         void (*kernel)(const f32x4 *, f32x4 *, int64_t) = gelu_vec_kernel<false, 1>;
         if (stream_past_caches) kernel = gelu_vec_kernel<true, 4>;
         else if (unroll == 4) kernel = gelu_vec_kernel<false, 4>;
-        hipLaunchKernelGGL(kernel, dim3((unsigned)((n4 + kThreads * unroll - 1) / (kThreads * unroll))), dim3(kThreads), 0, s,
-                           reinterpret_cast<const f32x4 *>(x), reinterpret_cast<f32x4 *>(y), n4);
+        const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+        f32x4 *y4 = reinterpret_cast<f32x4 *>(y);
+        int64_t count = n4;
+        void *args[] = {&x4, &y4, &count};
+        const hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(kernel),
+                                             dim3((unsigned)((n4 + kThreads * unroll - 1) / (kThreads * unroll))), dim3(kThreads), args, 0, s);
+        if (e != hipSuccess) return (int)e;
     }
-    const int64_t rest = n - 4 * n4;
-    if (rest > 0)
-        hipLaunchKernelGGL(gelu_scalar_kernel, dim3(grid_for(rest)), dim3(kThreads), 0, s, x + 4 * n4, y + 4 * n4, rest);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? CMHSA_OK : (int)e;
+    int64_t rest = n - 4 * n4;
+    if (rest > 0) {
+        const float *xr = x + 4 * n4;
+        float *yr = y + 4 * n4;
+        void *args[] = {&xr, &yr, &rest};
+        const hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(gelu_scalar_kernel), dim3(grid_for(rest)), dim3(kThreads), args, 0, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    return CMHSA_OK;
 }
 
 }  // extern "C"

@@ -108,6 +108,8 @@ at::Tensor causal_multihead_self_attention_decode(at::Tensor qkv_new, at::Tensor
         TORCH_CHECK(t->stride(t->dim() - 1) == 1, "last-dim stride must be 1");
     }
     TORCH_CHECK(pos.is_cuda() && pos.dtype() == at::kInt && pos.numel() == 1, "pos must be an int32 CUDA tensor with one element");
+    TORCH_CHECK(k_cache.device() == qkv_new.device() && v_cache.device() == qkv_new.device() && pos.device() == qkv_new.device(),
+                "qkv_new, k_cache, v_cache and pos must be on the same device");
     TORCH_CHECK(qkv_new.dim() == 2 && k_cache.dim() == 3 && v_cache.dim() == 3, "qkv_new must be (B, 3*d_model), caches (B, capacity, d_model)");
     TORCH_CHECK(num_heads > 0 && qkv_new.size(1) % (3 * num_heads) == 0, "last dimension of qkv_new must be 3 * d_model");
     const int64_t B = qkv_new.size(0), d = qkv_new.size(1) / 3, cap = k_cache.size(1);
@@ -115,7 +117,9 @@ at::Tensor causal_multihead_self_attention_decode(at::Tensor qkv_new, at::Tensor
     TORCH_CHECK(k_cache.sizes() == v_cache.sizes() && k_cache.strides() == v_cache.strides(), "k_cache and v_cache must have the same shape and strides");
     TORCH_CHECK(k_cache.size(0) == B && k_cache.size(2) == d, "cache shape must be (B, capacity, d_model)");
     TORCH_CHECK(B <= INT32_MAX && cap <= INT32_MAX, "shape exceeds 32-bit indexing");
-    at::Tensor output = at::empty({B, d}, qkv_new.options());
+    // zero-filled: a pos outside [0, capacity) makes the launch a no-op (include/cmhsa.h), and the op must not hand
+    // back uninitialised memory in that case
+    at::Tensor output = at::zeros({B, d}, qkv_new.options());
     if (output.numel() == 0) return output;
     const c10::hip::HIPGuard guard(qkv_new.device().index());
     const hipStream_t stream = c10::hip::getCurrentHIPStream(qkv_new.device().index()).stream();

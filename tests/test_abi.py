@@ -73,6 +73,11 @@ def test_argument_validation_needs_no_gpu():
     assert call(rs=(64, -64, 64, 64)) == cmhsa.CMHSA_ERR_BAD_SHAPE          # negative strides are not supported
     assert call(T=0) == cmhsa.CMHSA_OK          # empty sequence: successful no-op
     assert call(B=0) == cmhsa.CMHSA_OK
+    # the kernel forms 32-bit row numbers up to (ceil(T/32) + 16) * 32: a seq_len just over that bound is rejected
+    # explicitly, one far below it passes this check (and is then rejected for its grid size -- also before any launch)
+    assert call(T=2**31 - 1) == cmhsa.CMHSA_ERR_TOO_LARGE
+    assert call(T=2**31 - 512) == cmhsa.CMHSA_ERR_TOO_LARGE
+    assert call(rs=(2**24 + 4, 64, 64, 64)) == cmhsa.CMHSA_ERR_TOO_LARGE      # 32 rows * stride * 4 B must fit 32-bit offsets
     assert lib.cmhsa_fp32_fwd_2d(good, good, good, good, 100, 100, 100, 100, 8, 100, 3, null) == cmhsa.CMHSA_ERR_BAD_SHAPE
     assert lib.cmhsa_fp32_fwd_2d(good, good, good, good, 96, 96, 96, 96, 8, 96, 3, null) == cmhsa.CMHSA_ERR_HEAD_DIM
 

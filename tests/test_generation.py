@@ -254,3 +254,21 @@ def test_kv_cache_generation_on_gpu(gpu_device):
     assert e.generate(prompt) == [ref[0][:96]]
     g3 = gen.KVCacheGreedyGenerator(hip, 3, 128, device=gpu_device)
     assert g3.generate([prompt] * 3) == [ref[0][:128]] * 3
+
+
+@pytest.mark.gpu
+def test_gpt2_xl_width_batch8_tokens_identical_to_naive_on_gpu(gpu_device):
+    """BASELINE config 4's shape (GPT2-XL: H=25, d_model=1600, gpt2.py:70; 8 prompts per GPU at 8 GPUs) with the depth
+    overridden to 2 layers so the test stays short: batch 8, 64 total tokens, HIP kernel == naive formula on the same
+    GPU, every batch row identical (the prompts are copies), eager loop and HIP-graph loop."""
+    xl2 = dict(n_layers=2)
+    naive = gen.build_model("gpt2-xl", Backend.NAIVE_PYTORCH, gpu_device, overrides=xl2, seed=7)
+    hip = gen.build_model("gpt2-xl", Backend.CUSTOM_CUDA, gpu_device, overrides=xl2, seed=7)
+    assert hip.cfg["emb_dim"] == 1600 and hip.cfg["n_heads"] == 25 and len(hip.blocks) == 2
+    prompts = [list(gen.REFERENCE_PROMPT_IDS)] * 8
+    ref = gen.greedy_generate(naive, prompts, 64)
+    got = gen.greedy_generate(hip, prompts, 64)
+    assert got == ref
+    assert all(row == got[0] for row in got)
+    g = gen.BucketedGreedyGenerator(hip, 8, 64, bucket=32, device=gpu_device)
+    assert g.generate(prompts) == ref
