@@ -1,15 +1,24 @@
 """bench.py -- the hot path's headline measurement (BASELINE.json metric: attention fp32 TFLOP/s and
-% of MI355X fp32 MFMA peak).
+% of MI355X fp32 MFMA peak; GPT2 512-token generation seconds; 1-8 GPUs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config5_shard] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config5_shard|config5]
+                    [--no-cpu-baseline] [--no-extras] [--gen-budget SECONDS]
 
-A "step" is ONE pass of the hot path over one batch of synthetic input: one call of the C-ABI entry
-point cmhsa_fp32_fwd (one kernel launch) on inputs already resident in HBM.  Default workload =
-BASELINE.json configs[1]: standalone causal attention fp32, B=1, H=12, T=1024, d_head=64, inputs as
-the model hands them over (QKV column slices of one (T, 3*d_model) buffer).  With N > 1 every rank
-runs the same workload on its own GPU (independent prompts, data-parallel, no collective on the
-data path): weak scaling, value = aggregate over ranks.
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts N child ranks of itself
+(fresh processes, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, one per GPU), relays rank 0's JSON line and exits with the
+worst child status; it never touches the GPU.  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` works as well (the ranks then find WORLD_SIZE set).
+
+A "step" is ONE pass of the hot path over one batch of synthetic input: one call of the C-ABI entry point
+cmhsa_fp32_fwd_ws (one kernel launch) on inputs already resident in HBM.  Default workload = BASELINE.json configs[1]:
+standalone causal attention fp32, B=1, H=12, T=1024, d_head=64, inputs as the model hands them over (QKV column
+slices of one (T, 3*d_model) buffer).  With N > 1 every rank runs the same workload on its own GPU (independent
+prompts, data-parallel, no collective on the data path): weak scaling, value = aggregate over ranks.
+
+Timing: W warm-up steps, barrier + synchronize, a few untimed priming launches that refill the launch queue (a host
+fence drains it, and the ~30 us it takes to fill again would otherwise be billed to the first timed steps), then
+EXACTLY K steps between two HIP events on the launch stream, barrier + synchronize.  `value` and `ms_per_step` come
+from the events (max over ranks); the host wall clock around the same K steps is reported next to them.
 
 Flop convention: F = 2*B*H*d_head*T*(T+1) -- unmasked pairs only, softmax not counted.
 Rank 0 prints ONE JSON line.
@@ -20,7 +29,9 @@ import argparse
 import ctypes
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -29,9 +40,8 @@ for p in (ROOT, os.path.join(ROOT, "llm-inference_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 256 flop/clk/CU x 2.4 GHz (v_mfma_f32_32x32x2_f32)
+HBM_PEAK_GBPS = 8000.0
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -45,13 +55,50 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(wl: dict, budget_s: float = 20.0) -> dict:
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="config2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip other_workloads, generation and the N>1 config legs")
+    ap.add_argument("--gen-budget", type=float, default=100.0,
+                    help="seconds the generation legs (GPT2 512-token runs, config 1 on the CPU, config 4 sample) may take in all")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: this process starts the ranks and never initialises the GPU itself
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = {**os.environ, "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(args.gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    worst = max((abs(c) for c in codes), default=0)
+    if worst:
+        print(f"bench.py: child ranks exited with {codes}", file=sys.stderr)
+    return 1 if worst else 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(wl: dict, torch, budget_s: float = 20.0) -> dict:
     """The reference's CPU path (naive PyTorch formula on CPU tensors, restated in oracle/), timed on
     this host's cores on a bounded sample of the same workload."""
     from oracle import naive_attention as oracle
 
-    cores = os.cpu_count() or 1
-    cores = min(cores, 16) if "GRAFT_REPO_ROOT" in os.environ else cores   # the GPU box's CPU share is 16
+    cores = host_cores()
     torch.set_num_threads(cores)
     B = min(wl["B"], 2)                      # bounded sample: at most 2 batch rows of the workload
     H, T = wl["H"], wl["T"]
@@ -71,284 +118,472 @@ def cpu_baseline(wl: dict, budget_s: float = 20.0) -> dict:
                       f"at B={B} H={H} T={T}, median {med * 1e3:.2f} ms"}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", choices=list(WORKLOADS), default="config2")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def host_cores() -> int:
+    cores = os.cpu_count() or 1
+    return min(cores, 16) if "GRAFT_REPO_ROOT" in os.environ else cores   # the GPU box's CPU share is 16
 
-    if os.environ.get("CMHSA_BENCH_WATCHDOG"):               # debugging aid: dump every thread's stack and exit after N seconds
-        import faulthandler
 
-        faulthandler.dump_traceback_later(int(os.environ["CMHSA_BENCH_WATCHDOG"]), exit=True)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+class Bench:
+    """Everything one rank does.  `fwd_args(Q, K, V, out)` builds the C-ABI argument tuple once per workload, so the
+    timed loop is nothing but ctypes calls."""
+
+    def __init__(self, args):
+        import torch
+
+        self.torch = torch
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch N>1 either as `python bench.py --gpus N` "
+                             "(it starts its own ranks) or with python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP attention path has no CPU fallback")
-    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (never for reported numbers):
-    # CMHSA_BENCH_BACKEND=gloo lets several ranks share a card (RCCL refuses two ranks on one device)
-    backend = os.environ.get("CMHSA_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP attention path has no CPU fallback")
+        # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (never for reported numbers):
+        # CMHSA_BENCH_BACKEND=gloo lets several ranks share a card (RCCL refuses two ranks on one device)
+        self.backend = os.environ.get("CMHSA_BENCH_BACKEND", "nccl")
+        dev_index = local_rank % torch.cuda.device_count() if self.backend != "nccl" else local_rank
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(self.backend, **({"device_id": self.dev} if self.backend == "nccl" else {}))
+            self.dist = dist
+        import cmhsa
 
-    import cmhsa
+        self.cmhsa = cmhsa
+        self.lib = cmhsa.load_library()
+        self.stream = torch.cuda.current_stream(self.dev)
+        self.workspace = cmhsa.Workspace(self.dev)                  # device scratch of the split plans, zeroed once
 
-    lib = cmhsa.load_library()
-    wl = WORKLOADS[args.workload]
-    B, H, T = wl["B"], wl["H"], wl["T"]
-    if backend != "nccl":
-        B, T = min(B, 2), min(T, 1024)                   # rehearsal only: keep the host-staged collective small
-    sharded = bool(wl.get("head_sharded"))
-    if sharded:
-        if H % world != 0:
-            raise SystemExit(f"config5 needs num_heads ({H}) divisible by the number of GPUs ({world})")
-        H = H // world                                   # this rank's heads: a column slab of Q, K, V
-    d = 64 * H
-    torch.manual_seed(1234 + rank)
-    qkv = torch.rand((B, T, 3 * d), device=dev)                      # reference test distribution (test_torch_extension.py:16-18)
-    Q, K, V = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]      # row stride 3*d_model, as in the model
-    out = torch.empty((B, T, d), device=dev)
-    stream = torch.cuda.current_stream(dev)
-    call_args = (Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
-                 Q.stride(1), K.stride(1), V.stride(1), out.stride(1),
-                 Q.stride(0), K.stride(0), V.stride(0), out.stride(0),
-                 B, T, H, 64, ctypes.c_void_p(stream.cuda_stream))
-    fwd = lib.cmhsa_fp32_fwd
+    # -- helpers --------------------------------------------------------------------------------------------------
+    def fence(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
 
-    gathered = torch.empty((world * B, T, d), device=dev) if sharded and world > 1 else None
+    def max_over_ranks(self, *vals: float):
+        if self.dist is None:
+            return vals
+        t = self.torch.tensor(vals, device=self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return tuple(float(x) for x in t)
 
-    def step() -> None:
-        rc = fwd(*call_args)
+    def sliced_inputs(self, B: int, T: int, H: int, maker=None):
+        torch = self.torch
+        d = 64 * H
+        qkv = (maker or torch.rand)((B, T, 3 * d), device=self.dev)    # reference test distribution (test_torch_extension.py:16-18)
+        return qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]          # row stride 3*d_model, as in the model
+
+    def fwd_args(self, Q, K, V, out, B, T, H):
+        return (Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
+                Q.stride(1), K.stride(1), V.stride(1), out.stride(1),
+                Q.stride(0), K.stride(0), V.stride(0), out.stride(0),
+                B, T, H, 64, self.workspace.ptr, self.workspace.nbytes, ctypes.c_void_p(self.stream.cuda_stream))
+
+    def launch(self, a) -> None:
+        rc = self.lib.cmhsa_fp32_fwd_ws(*a)
         if rc != 0:
-            raise RuntimeError(cmhsa.status_string(rc))
-        if gathered is not None:                         # the one collective of the head-sharded form
-            dist.all_gather_into_tensor(gathered, out)
+            raise RuntimeError(self.cmhsa.status_string(rc))
 
-    def fence() -> None:
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)          # same stream the kernel is launched on
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    fence()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-
-    clock_mhz = cmhsa.sustained_shader_clock_mhz(dev)       # outside the timed region; SURVEY 8(d): print the clock
-    # parity spot-check outside the timed region: one (batch, head) against the f64 oracle
-    from oracle import naive_attention as oracle
-    sl = slice(64 * (H - 1), 64 * H)
-    want = oracle.naive_attention_f64(Q[B - 1, :, sl].cpu().numpy(), K[B - 1, :, sl].cpu().numpy(), V[B - 1, :, sl].cpu().numpy(), 1)
-    max_err = float(abs(out[B - 1, :, sl].cpu().numpy() - want).max())
-
-    breakdown = None
-    if gathered is not None:
-        # compute-only rate per GPU and the all-gather on its own (outside the timed region)
-        def span(fn, reps=5):
+    def events_us(self, fn, reps: int, warm: int = 20) -> float:
+        """Steady-state time per call: `warm` untimed calls, then `reps` calls between two events, no host fence
+        in between (the queue stays full across the boundary)."""
+        torch = self.torch
+        for _ in range(warm):
             fn()
-            fence()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            for _ in range(reps):
-                fn()
-            b.record(stream)
-            fence()
-            return a.elapsed_time(b) / reps
-        comp_ms = span(lambda: fwd(*call_args))
-        ag_ms = span(lambda: dist.all_gather_into_tensor(gathered, out))
-        t2 = torch.tensor([comp_ms, ag_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        comp_ms, ag_ms = float(t2[0]), float(t2[1])
-        recv_bytes = (world - 1) * out.numel() * 4
-        breakdown = {"compute_only_ms": round(comp_ms, 4),
-                     "compute_only_tflops_per_gpu": round(cmhsa.algorithmic_flops(B, T, H, 64) / (comp_ms * 1e-3) / 1e12, 2),
-                     "all_gather_ms": round(ag_ms, 4), "all_gather_received_bytes_per_rank": recv_bytes,
-                     "all_gather_GBps_received_per_rank": round(recv_bytes / (ag_ms * 1e-3) / 1e9, 1),
-                     "all_gather_GBps_per_xgmi_link": round(recv_bytes / (world - 1) / (ag_ms * 1e-3) / 1e9, 1)}
-    if world > 1:
-        tmax = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(tmax[0]), float(tmax[1])
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(self.stream)
+        for _ in range(reps):
+            fn()
+        b.record(self.stream)
+        torch.cuda.synchronize(self.dev)
+        return a.elapsed_time(b) * 1e3 / reps
 
-    flops = cmhsa.algorithmic_flops(B, T, H, 64)              # per rank
-    ms_per_step = wall * 1e3 / args.steps
-    value = world * flops / (wall / args.steps) / 1e12
-    launch_us = dev_ms * 1e3 / args.steps
-    achieved = flops / (dev_ms * 1e-3 / args.steps) / 1e12
+    # -- the headline ---------------------------------------------------------------------------------------------
+    def headline(self) -> dict:
+        torch, args, world = self.torch, self.args, self.world
+        wl = WORKLOADS[args.workload]
+        B, H, T = wl["B"], wl["H"], wl["T"]
+        if self.backend != "nccl":
+            B, T = min(B, 2), min(T, 1024)                   # rehearsal only: keep the host-staged collective small
+        sharded = bool(wl.get("head_sharded"))
+        if sharded:
+            if H % world != 0:
+                raise SystemExit(f"config5 needs num_heads ({H}) divisible by the number of GPUs ({world})")
+            H = H // world                                   # this rank's heads: a column slab of Q, K, V
+        d = 64 * H
+        torch.manual_seed(1234 + self.rank)
+        Q, K, V = self.sliced_inputs(B, T, H)
+        out = torch.empty((B, T, d), device=self.dev)
+        call_args = self.fwd_args(Q, K, V, out, B, T, H)
+        gathered = torch.empty((world * B, T, d), device=self.dev) if sharded and world > 1 else None
 
-    # HBM traffic per launch from the committed rocprofv3 counter passes of this same workload
-    # (tools/prof_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, KiB -> bytes)
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_summary.json")
-    if os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
+        def step() -> None:
+            self.launch(call_args)
+            if gathered is not None:                         # the one collective of the head-sharded form
+                self.dist.all_gather_into_tensor(gathered, out)
 
-    # secondary evidence (N=1 only, outside the timed region): the throughput-regime shape
-    others = {}
-    if world == 1 and args.workload == "config2":
-        for name in ("config5_shard",):
-            o = WORKLOADS[name]
-            x = torch.rand((o["B"], o["T"], 3 * 64 * o["H"]), device=dev)
-            dd = 64 * o["H"]
-            oq, ok, ov = x[..., :dd], x[..., dd:2 * dd], x[..., 2 * dd:]
-            oo = torch.empty((o["B"], o["T"], dd), device=dev)
-            a = (oq.data_ptr(), ok.data_ptr(), ov.data_ptr(), oo.data_ptr(), oq.stride(1), ok.stride(1), ov.stride(1), oo.stride(1),
-                 oq.stride(0), ok.stride(0), ov.stride(0), oo.stride(0), o["B"], o["T"], o["H"], 64, ctypes.c_void_p(stream.cuda_stream))
-            for _ in range(3):
-                fwd(*a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(10):
-                fwd(*a)
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            us = e0.elapsed_time(e1) * 1e3 / 10
-            tf = cmhsa.algorithmic_flops(o["B"], o["T"], o["H"], 64) / us / 1e6
-            others[name] = {"workload": o["desc"], "us_per_launch": round(us, 2), "tflops": round(tf, 2),
-                            "frac_of_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
-            del x, oo
+        for _ in range(args.warmup):
+            step()
+        self.fence()
+        prime = min(8, max(args.warmup, 1))
+        for _ in range(prime):                               # refill the launch queue the fence has drained (untimed)
+            step()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(self.stream)                              # same stream the kernel is launched on
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ev1.record(self.stream)
+        self.fence()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        wall, dev_ms = self.max_over_ranks(wall, dev_ms)
+
+        clock_mhz = self.cmhsa.sustained_shader_clock_mhz(self.dev)       # outside the timed region; SURVEY 8(d): print the clock
+        # parity spot-check outside the timed region: one (batch, head) against the f64 oracle
+        from oracle import naive_attention as oracle
+        sl = slice(64 * (H - 1), 64 * H)
+        want = oracle.naive_attention_f64(Q[B - 1, :, sl].cpu().numpy(), K[B - 1, :, sl].cpu().numpy(), V[B - 1, :, sl].cpu().numpy(), 1)
+        max_err = float(abs(out[B - 1, :, sl].cpu().numpy() - want).max())
+
+        flops = self.cmhsa.algorithmic_flops(B, T, H, 64)              # per rank
+        step_s = dev_ms * 1e-3 / args.steps
+        achieved = flops / step_s / 1e12
+
+        # HBM traffic per launch from the committed rocprofv3 counter passes of this same workload
+        # (tools/prof_all.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, KiB -> bytes)
+        traffic, traffic_source = None, None
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}_summary.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
+                traffic_source = f"profiles/pmc_{args.workload}_summary.json (rocprofv3 --pmc passes of this workload, committed; not measured in this run)"
+
+        result = {
+            "metric": "attention fp32 TFLOP/s (causal MHSA forward, F = 2*B*H*d*T*(T+1))",
+            "value": round(world * achieved, 3),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 6),
+            "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (torch.rand U[0,1), seeded), inputs resident in HBM",
+            "config": {"workload": wl["desc"], "batch_per_gpu": B, "num_heads": H, "seq_len": T, "head_dim": 64,
+                       "parallelism": (f"heads/{world} per GPU + one all-gather of (B,T,{d}) fp32 slabs" if sharded else
+                                       f"dp{world} (independent prompts per GPU, no data-path collective)")},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "cmhsa_fwd_kernel", "avg_launch_us": round(step_s * 1e6, 3),
+                         "flops_per_launch": flops, "bytes_per_launch_algorithmic": 4 * B * T * d * 4,
+                         "timing": "HIP events on the launch stream around the K timed steps, launch queue kept full across "
+                                   "the warm-up boundary (includes inter-launch gaps)"},
+            "timing": {"value_from": "HIP events on the launch stream (max over ranks)",
+                       "wall_ms_per_step_incl_final_fence": round(wall * 1e3 / args.steps, 6),
+                       "value_from_wall_clock": round(world * flops / (wall / args.steps) / 1e12, 3),
+                       "priming_launches_after_fence": prime},
+            "percent_of_fp32_mfma_peak": round(100 * achieved / FP32_MFMA_PEAK_TFLOPS, 2),
+            "max_abs_err_vs_f64_oracle": max_err,
+            "peak_assumes_clock_mhz": 2400,
+            "sustained_shader_clock_mhz_under_fp32_mfma_load": round(clock_mhz, 0),
+            "entry_point": "cmhsa_fp32_fwd_ws",
+            "plan": self.cmhsa.plan_description(B, T, H, self.workspace.nbytes),
+            "device": torch.cuda.get_device_name(self.dev),
+        }
+        if self.backend != "nccl":
+            result["data"] += f"; REHEARSAL with backend {self.backend}: ranks may share a GPU, numbers are not measurements"
+        if gathered is not None and not args.no_extras:
+            result["config5_breakdown"] = self.config5_breakdown(B, T, wl["H"])
+        return result
+
+    # -- secondary kernel evidence (N = 1) ------------------------------------------------------------------------
+    def other_workloads(self) -> dict:
+        torch, lib = self.torch, self.lib
+        others = {}
+        o = WORKLOADS["config5_shard"]
+        q, k, v = self.sliced_inputs(o["B"], o["T"], o["H"])
+        oo = torch.empty((o["B"], o["T"], 64 * o["H"]), device=self.dev)
+        a = self.fwd_args(q, k, v, oo, o["B"], o["T"], o["H"])
+        us = self.events_us(lambda: self.launch(a), reps=20, warm=20)
+        tf = self.cmhsa.algorithmic_flops(o["B"], o["T"], o["H"], 64) / us / 1e6
+        others["config5_shard"] = {"workload": o["desc"], "us_per_launch": round(us, 2), "tflops": round(tf, 2),
+                                   "frac_of_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "warmup": 20, "reps": 20}
+        del q, k, v, oo
         # SURVEY 8(d) config 2 asks for more than the headline: contiguous as well as QKV-sliced inputs, randn as well
         # as rand, and the latency of ONE launch (launch -> completion seen by the host) next to the back-to-back rate
-        def timed(fn, reps):
-            for _ in range(5):
-                fn()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            for _ in range(reps):
-                fn()
-            b.record(stream)
-            torch.cuda.synchronize(dev)
-            return a.elapsed_time(b) * 1e3 / reps
-
+        c2 = WORKLOADS["config2"]
+        B, T, H = c2["B"], c2["T"], c2["H"]
+        d = 64 * H
+        out = torch.empty((B, T, d), device=self.dev)
         variants = {}
-        for vname, maker, sliced in (("contiguous_rand", torch.rand, False), ("qkv_sliced_randn", torch.randn, True), ("contiguous_randn", torch.randn, False)):
+        for vname, maker, sliced in (("qkv_sliced_rand", torch.rand, True), ("contiguous_rand", torch.rand, False),
+                                     ("qkv_sliced_randn", torch.randn, True), ("contiguous_randn", torch.randn, False)):
             if sliced:
-                x = maker((B, T, 3 * d), device=dev)
-                vq, vk, vv = x[..., :d], x[..., d:2 * d], x[..., 2 * d:]
+                vq, vk, vv = self.sliced_inputs(B, T, H, maker)
             else:
-                vq, vk, vv = (maker((B, T, d), device=dev) for _ in range(3))
-            va = (vq.data_ptr(), vk.data_ptr(), vv.data_ptr(), out.data_ptr(), vq.stride(1), vk.stride(1), vv.stride(1), out.stride(1),
-                  vq.stride(0), vk.stride(0), vv.stride(0), out.stride(0), B, T, H, 64, ctypes.c_void_p(stream.cuda_stream))
-            variants[vname + "_us"] = round(timed(lambda: fwd(*va), 200), 3)
+                vq, vk, vv = (maker((B, T, d), device=self.dev) for _ in range(3))
+            va = self.fwd_args(vq, vk, vv, out, B, T, H)
+            variants[vname + "_us"] = round(self.events_us(lambda: self.launch(va), reps=200, warm=20), 3)
+        # the entry point without a workspace never splits a query block across workgroups
+        vq, vk, vv = self.sliced_inputs(B, T, H)
+        na = self.fwd_args(vq, vk, vv, out, B, T, H)[:16] + (ctypes.c_void_p(self.stream.cuda_stream),)
+        variants["no_workspace_entry_point_cmhsa_fp32_fwd_us"] = round(self.events_us(lambda: lib.cmhsa_fp32_fwd(*na), reps=200, warm=20), 3)
         lat = []
+        va = self.fwd_args(vq, vk, vv, out, B, T, H)
         for _ in range(50):
-            torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(self.dev)
             t1 = time.perf_counter()
-            fwd(*call_args)
-            torch.cuda.synchronize(dev)
+            self.launch(va)
+            torch.cuda.synchronize(self.dev)
             lat.append((time.perf_counter() - t1) * 1e6)
         variants["single_launch_host_latency_us_median"] = round(statistics.median(lat), 2)
         others["config2_variants"] = variants
+        sp = ctypes.c_void_p(self.stream.cuda_stream)
         # the fused tanh-GELU kernel (SURVEY 8(f) row 3): HBM-bound, 8 algorithmic bytes per element
         for name, n in (("gelu_gpt2xl_b64_t512", 64 * 512 * 6400), ("gelu_gpt2_t256", 256 * 3072)):
-            gx = torch.randn(n, device=dev)
+            gx = torch.randn(n, device=self.dev)
             gy = torch.empty_like(gx)
-            ga = (gx.data_ptr(), gy.data_ptr(), n, ctypes.c_void_p(stream.cuda_stream))
-            for _ in range(3):
-                lib.gpt2_gelu_tanh_f32_fwd(*ga)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 20
-            e0.record(stream)
-            for _ in range(reps):
-                lib.gpt2_gelu_tanh_f32_fwd(*ga)
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            us = e0.elapsed_time(e1) * 1e3 / reps
+            ga = (gx.data_ptr(), gy.data_ptr(), n, sp)
+            us = self.events_us(lambda: lib.gpt2_gelu_tanh_f32_fwd(*ga), reps=20, warm=20)
             gbs = lib.gpt2_gelu_algorithmic_bytes(n) / us / 1e3
             others[name] = {"workload": f"fused tanh-GELU fp32, {n} elements", "us_per_launch": round(us, 2),
-                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                                         "frac": round(gbs / 8000.0, 4), "traffic": None}}
+                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": round(gbs / HBM_PEAK_GBPS, 4), "traffic": None}}
             del gx, gy
         # the KV-cache decode step (SURVEY 8(f) row 4, opt-in): HBM/L2-bound, reads every cached K and V row once
         for name, (db, dh, keys) in (("decode_b64_h25_k512", (64, 25, 512)), ("decode_b1_h12_k512", (1, 12, 512))):
             dd = 64 * dh
-            kc = torch.randn((db, keys, dd), device=dev)
-            vc = torch.randn((db, keys, dd), device=dev)
-            new = torch.randn((db, 3 * dd), device=dev)
-            do = torch.empty((db, dd), device=dev)
-            pos = torch.tensor([keys - 1], dtype=torch.int32, device=dev)
+            kc = torch.randn((db, keys, dd), device=self.dev)
+            vc = torch.randn((db, keys, dd), device=self.dev)
+            new = torch.randn((db, 3 * dd), device=self.dev)
+            do = torch.empty((db, dd), device=self.dev)
+            pos = torch.tensor([keys - 1], dtype=torch.int32, device=self.dev)
             da = (new.data_ptr(), new.stride(0), kc.data_ptr(), vc.data_ptr(), kc.stride(1), kc.stride(0), do.data_ptr(), do.stride(0),
-                  pos.data_ptr(), db, keys, dh, 64, ctypes.c_void_p(stream.cuda_stream))
-            for _ in range(3):
-                lib.cmhsa_fp32_decode_step(*da)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 50
-            e0.record(stream)
-            for _ in range(reps):
-                lib.cmhsa_fp32_decode_step(*da)
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            us = e0.elapsed_time(e1) * 1e3 / reps
+                  pos.data_ptr(), db, keys, dh, 64, sp)
+            us = self.events_us(lambda: lib.cmhsa_fp32_decode_step(*da), reps=50, warm=20)
             gbs = lib.cmhsa_decode_algorithmic_bytes(db, keys, dh, 64) / us / 1e3
             others[name] = {"workload": f"KV-cache decode step fp32, B={db} H={dh}, {keys} keys", "us_per_launch": round(us, 2),
-                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                                         "frac": round(gbs / 8000.0, 4), "traffic": None}}
+                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": round(gbs / HBM_PEAK_GBPS, 4), "traffic": None}}
             del kc, vc
-    result = {
-        "metric": "attention fp32 TFLOP/s (causal MHSA forward, F = 2*B*H*d*T*(T+1))",
-        "value": round(value, 3),
-        "unit": "TFLOP/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 6),
-        "higher_is_better": True,
-        "scaling": "strong" if sharded else "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic (torch.rand U[0,1), seeded), inputs resident in HBM",
-        "config": {"workload": wl["desc"], "batch_per_gpu": B, "num_heads": H, "seq_len": T, "head_dim": 64,
-                   "parallelism": (f"heads/{world} per GPU + one all-gather of (B,T,{d}) fp32 slabs" if sharded else
-                                   f"dp{world} (independent prompts per GPU, no data-path collective)")},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "kernel": "cmhsa_fwd_kernel", "avg_launch_us": round(launch_us, 3),
-                     "flops_per_launch": flops, "bytes_per_launch_algorithmic": 4 * B * T * d * 4,
-                     "timing": "HIP events on the launch stream around the timed steps (includes inter-launch gaps)"},
-        "percent_of_fp32_mfma_peak": round(100 * achieved / FP32_MFMA_PEAK_TFLOPS, 2),
-        "max_abs_err_vs_f64_oracle": max_err,
-        "peak_assumes_clock_mhz": 2400,
-        "sustained_shader_clock_mhz_under_fp32_mfma_load": round(clock_mhz, 0),
-        "device": torch.cuda.get_device_name(dev),
-    }
-    if backend != "nccl":
-        result["data"] += f"; REHEARSAL with backend {backend}: ranks may share a GPU, numbers are not measurements"
-    if others:
-        result["other_workloads"] = others
-    if breakdown:
-        result["config5_breakdown"] = breakdown
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(wl)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
+        return others
+
+    # -- generation (the metric's first clause: GPT2 512-token seconds; BASELINE configs 1 and 3) -----------------
+    def generation(self, budget_s: float) -> dict:
+        """GPT2 greedy generation to 512 total tokens from the reference prompt, B=1, seeded random weights (no
+        checkpoint offline): the reference loop with the naive formula and with this kernel on the same GPU, the
+        HIP-graph loop with the fused GELU, tokens compared; the larger models and config 1 (naive PyTorch on the
+        host CPU) as far as the time budget reaches."""
+        torch = self.torch
+        import gpt2_generation as gen
+        from causal_self_attention import ScaledDotProductAttentionBackend as Backend
+
+        t_start = time.perf_counter()
+        left = lambda: budget_s - (time.perf_counter() - t_start)
+        prompt = list(gen.REFERENCE_PROMPT_IDS)
+        res = {"prompt": "reference prompt ids (8 tokens)", "max_tokens": 512, "batch": 1, "weights": "seeded random (no checkpoint offline)",
+               "note": "seconds = the second, timed run as reference gpt2.py:104-134 (warm-up run first)"}
+
+        def run(model_name, backend, graphs, fused):
+            # the small model's weights are drawn on the CPU so that config 1 (CPU) and config 3 (GPU) run the SAME model
+            model = gen.build_model(model_name, backend, self.dev, seed=0, fused_gelu=fused, init_on_device=model_name != "gpt2")
+            g = gen.BucketedGreedyGenerator(model, 1, 512, bucket=64, device=self.dev) if graphs else None
+            t = gen.time_greedy_generation(model, prompt, 512, self.dev, g)
+            n_new = len(t.tokens[0]) - len(prompt)
+            del g, model
+            torch.cuda.empty_cache()
+            return t.tokens[0], {"seconds": round(t.second_run_seconds, 4), "tokens_generated": n_new,
+                                 "tokens_per_second": round(n_new / t.second_run_seconds, 1)}
+
+        small = {}
+        tok_naive, small["reference_loop_naive_attention"] = run("gpt2", Backend.NAIVE_PYTORCH, False, False)
+        tok_hip, small["reference_loop_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, False, False)
+        tok_graph, small["hip_graphs_fused_gelu_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, True, True)
+        small["tokens_identical_naive_vs_hip_vs_graphs"] = bool(tok_naive == tok_hip == tok_graph)
+        # attention share: the 504 x 12 attention launches of that generation (T = 8..511, H = 12) replayed on their own
+        H, d = 12, 768
+        qkv = torch.rand((1, 512, 3 * d), device=self.dev)
+        out = torch.empty((1, 512, d), device=self.dev)
+        launches = []
+        for T in range(8, 512):
+            q, k, v = qkv[:, :T, :d], qkv[:, :T, d:2 * d], qkv[:, :T, 2 * d:]
+            launches.append(self.fwd_args(q, k, v, out[:, :T], 1, T, H))
+        def replay():
+            for a in launches:
+                for _ in range(12):
+                    self.launch(a)
+        replay()
+        torch.cuda.synchronize(self.dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(self.stream)
+        replay()
+        e1.record(self.stream)
+        torch.cuda.synchronize(self.dev)
+        att_s = e0.elapsed_time(e1) * 1e-3
+        small["attention_kernel_seconds_6048_launches"] = round(att_s, 4)
+        small["attention_share_of_reference_loop_hip"] = round(att_s / small["reference_loop_hip_kernel"]["seconds"], 4)
+        small["attention_share_of_hip_graph_loop"] = round(att_s / small["hip_graphs_fused_gelu_hip_kernel"]["seconds"], 4)
+        res["gpt2"] = small
+        del qkv, out, launches
+        for name, est in (("gpt2-medium", 8.0), ("gpt2-large", 14.0), ("gpt2-xl", 22.0)):
+            if left() < est:
+                res[name] = "skipped: generation time budget (--gen-budget) spent"
+                continue
+            _, r = run(name, Backend.CUSTOM_CUDA, True, True)
+            res[name] = {"hip_graphs_fused_gelu_hip_kernel": r}
+        # config 1: naive PyTorch attention on the host CPU (reference loop), all of this host's cores
+        if left() >= 45.0:
+            cores = host_cores()
+            torch.set_num_threads(cores)
+            model = gen.build_model("gpt2", Backend.NAIVE_PYTORCH, "cpu", seed=0)
+            t = gen.time_greedy_generation(model, prompt, 512, "cpu")
+            n_new = len(t.tokens[0]) - len(prompt)
+            res["config1_cpu_naive"] = {"seconds": round(t.second_run_seconds, 3), "tokens_generated": n_new,
+                                        "tokens_per_second": round(n_new / t.second_run_seconds, 2), "cores": cores,
+                                        "tokens_identical_to_gpu_naive": bool(t.tokens[0] == tok_naive)}
+        else:
+            res["config1_cpu_naive"] = "skipped: generation time budget (--gen-budget) spent"
+        res["seconds_spent"] = round(time.perf_counter() - t_start, 1)
+        return res
+
+    # -- N > 1: config 5 through sharded_attention, config 4 data-parallel -----------------------------------------
+    def config5_breakdown(self, B: int, T: int, H_total: int) -> dict:
+        """BASELINE configs[4] through llm-inference_amd/sharded_attention.py with the HIP kernel as `compute`:
+        compute only (this rank's heads), the all-gather on its own, and end to end including the
+        (W, B, T, slab) -> (B, T, H*64) permute."""
+        torch, dist, world = self.torch, self.dist, self.world
+        import sharded_attention as sa
+
+        d = 64 * H_total
+        torch.manual_seed(77)                                   # same inputs on every rank, as head sharding assumes
+        Q, K, V = self.sliced_inputs(B, T, H_total)
+        compute = lambda q, k, v, h: self.cmhsa.attention_fwd(q, k, v, h, workspace=self.workspace)
+        per = H_total // world
+
+        def span(fn, reps=5, warm=2):
+            for _ in range(warm):
+                fn()
+            self.fence()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(self.stream)
+            for _ in range(reps):
+                fn()
+            b.record(self.stream)
+            self.fence()
+            return a.elapsed_time(b) / reps
+
+        slab = sa.head_sharded_attention(Q, K, V, H_total, compute, gather=False).contiguous()
+        flat = torch.empty((world * B, T, 64 * per), device=self.dev)
+        comp_ms = span(lambda: sa.head_sharded_attention(Q, K, V, H_total, compute, gather=False))
+        ag_ms = span(lambda: dist.all_gather_into_tensor(flat, slab))
+        e2e_ms = span(lambda: sa.head_sharded_attention(Q, K, V, H_total, compute))
+        comp_ms, ag_ms, e2e_ms = self.max_over_ranks(comp_ms, ag_ms, e2e_ms)
+        full = sa.head_sharded_attention(Q, K, V, H_total, compute)
+        # parity of the gathered result: one head this rank did NOT compute, against the f64 oracle
+        from oracle import naive_attention as oracle
+        h = ((self.rank + 1) % world) * per
+        sl = slice(64 * h, 64 * h + 64)
+        want = oracle.naive_attention_f64(Q[0, :, sl].cpu().numpy(), K[0, :, sl].cpu().numpy(), V[0, :, sl].cpu().numpy(), 1)
+        err = float(abs(full[0, :, sl].cpu().numpy() - want).max())
+        (err,) = self.max_over_ranks(err)
+        recv = (world - 1) * slab.numel() * 4
+        total_flops = self.cmhsa.algorithmic_flops(B, T, H_total, 64)
+        return {"via": "sharded_attention.head_sharded_attention(compute=cmhsa.attention_fwd)",
+                "compute_only_ms": round(comp_ms, 4),
+                "compute_only_tflops_per_gpu": round(total_flops / world / (comp_ms * 1e-3) / 1e12, 2),
+                "all_gather_ms": round(ag_ms, 4), "all_gather_received_bytes_per_rank": recv,
+                "all_gather_GBps_received_per_rank": round(recv / (ag_ms * 1e-3) / 1e9, 1),
+                "end_to_end_ms_incl_permute": round(e2e_ms, 4),
+                "end_to_end_tflops_all_gpus": round(total_flops / (e2e_ms * 1e-3) / 1e12, 2),
+                "gathered_max_abs_err_vs_f64_oracle": err,
+                "note": "GB/s is per rank over all its links together; the per-link rate depends on how RCCL routes the collective"}
+
+    def config5_leg(self) -> dict | str:
+        wl = WORKLOADS["config5"]
+        if wl["H"] % self.world != 0:
+            return f"skipped: {wl['H']} heads do not divide over {self.world} GPUs"
+        B, T = wl["B"], wl["T"]
+        if self.backend != "nccl":
+            B, T = 2, 512
+        return self.config5_breakdown(B, T, wl["H"])
+
+    def config4_dp_leg(self, budget_s: float) -> dict | str:
+        """BASELINE configs[3]: GPT2-XL, 64 copies of the reference prompt split evenly over the ranks (data-parallel,
+        replicated weights, no collective on the data path), HIP-graph loop + fused GELU.  A bounded sample: the total
+        length is 72 tokens (64 generated per prompt) unless the budget allows the full 512."""
+        torch = self.torch
+        import gpt2_generation as gen
+        from causal_self_attention import ScaledDotProductAttentionBackend as Backend
+
+        if budget_s < 30:
+            return "skipped: generation time budget (--gen-budget) spent"
+        n_prompts, max_tokens = 64, 72
+        model_name = "gpt2-xl"
+        overrides = None
+        if self.backend != "nccl":
+            n_prompts, overrides = 8, dict(n_layers=2)
+        mine = gen.shard_prompts(n_prompts, self.rank, self.world)
+        prompts = [list(gen.REFERENCE_PROMPT_IDS) for _ in mine]
+        model = gen.build_model(model_name, Backend.CUSTOM_CUDA, self.dev, seed=0, fused_gelu=True, init_on_device=True, overrides=overrides)
+        g = gen.BucketedGreedyGenerator(model, len(prompts), max_tokens, bucket=64, device=self.dev)
+        g.generate(prompts)                                      # captures the graphs (warm-up)
+        self.fence()
+        t0 = time.perf_counter()
+        toks = g.generate(prompts)
+        torch.cuda.synchronize(self.dev)
+        seconds = time.perf_counter() - t0
+        generated = float(sum(len(t) - len(gen.REFERENCE_PROMPT_IDS) for t in toks))
+        (seconds,) = self.max_over_ranks(seconds)
+        if self.dist is not None:
+            t = torch.tensor([generated], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(t)
+            generated = float(t[0])
+        rows_equal = all(row == toks[0] for row in toks)
+        del g, model
+        torch.cuda.empty_cache()
+        return {"workload": f"{model_name} fp32, {n_prompts} prompts over {self.world} GPU(s) ({len(prompts)} on rank 0), "
+                            f"{max_tokens} total tokens each (bounded sample of the 512-token config), HIP graphs + fused GELU",
+                "seconds": round(seconds, 3), "tokens_generated_all_gpus": int(generated),
+                "tokens_per_second_all_gpus": round(generated / seconds, 1), "rows_identical_on_rank0": bool(rows_equal)}
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if os.environ.get("CMHSA_BENCH_WATCHDOG"):               # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["CMHSA_BENCH_WATCHDOG"]), exit=True)
+    b = Bench(args)
+    result = b.headline()
+    if not args.no_extras:
+        t0 = time.perf_counter()
+        if b.world == 1 and args.workload == "config2":
+            result["other_workloads"] = b.other_workloads()
+            result["other_workloads"]["generation"] = b.generation(args.gen_budget)
+        if b.world > 1 and args.workload == "config2":
+            result["config5"] = b.config5_leg()
+            result["config4_dp"] = b.config4_dp_leg(args.gen_budget)
+        result["extras_seconds"] = round(time.perf_counter() - t0, 1)
+    if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], b.torch)
+    if b.dist is not None:
+        b.dist.barrier()
+        b.dist.destroy_process_group()
+    if b.rank == 0:
         print(json.dumps(result), flush=True)
 
 

@@ -14,6 +14,7 @@
 #ifndef CMHSA_H
 #define CMHSA_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -29,6 +30,7 @@ extern "C" {
 #define CMHSA_ERR_HEAD_DIM      -3   /* head_dim != 64          (CMHSA.cu:432 "Head dimension must be 64") */
 #define CMHSA_ERR_ALIGNMENT     -4   /* pointer not 16-B aligned or stride % 4 != 0 (CMHSA.cu:480-486)     */
 #define CMHSA_ERR_TOO_LARGE     -5   /* grid or 32-bit tile index would overflow                   */
+#define CMHSA_ERR_WORKSPACE     -6   /* workspace too small                                         */
 
 /* Human-readable text for a status code returned by this library (static storage). */
 const char *cmhsa_status_string(int status);
@@ -63,6 +65,42 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
                    int batch, int seq_len, int num_heads, int head_dim,
                    void *stream);
 
+/* The same forward with a WORKSPACE -- the fastest entry point on grids of about one round of the chip's CUs
+ * (BASELINE config 2: B=1, H=12, T=1024).  The reference's grid is one block per (query tile, head) with no
+ * inter-block communication (CMHSA.cu:425); with only device memory of the caller's this library can likewise only
+ * give whole query blocks to workgroups, and the longest block then sets the kernel's time.  Given a workspace, the
+ * planner may cut a query block's KEYS into two ranges held by different workgroups; each stores its un-normalised
+ * (O, m, l) to the workspace and the workgroup that finishes last merges them (no workgroup waits for another, the
+ * merge order is fixed: results are bitwise reproducible and within rounding of cmhsa_fp32_fwd's).
+ *
+ *   workspace        : device memory, 256-B aligned, hipMalloc'd (or from a pool of such memory, e.g. torch's caching
+ *                      allocator).  CMHSA_WORKSPACE_BYTES always suffices; cmhsa_fp32_fwd_workspace_bytes() gives
+ *                      the exact need of one shape (0 for shapes whose plan splits nothing).
+ *   workspace_bytes  : its size.  NULL / 0 / too short is not an error: the call then uses the plan that needs none
+ *                      (= cmhsa_fp32_fwd).
+ * Before its FIRST use (and after a launch that did not run to completion) the workspace's counter block must be
+ * zero: cmhsa_workspace_init().  Every completed launch leaves it zero again.  Calls that overlap in time on one GPU
+ * must not share a workspace (one per stream). */
+#define CMHSA_WORKSPACE_BYTES ((size_t)(16384 + 1024 * (2048 + 64) * 4))     /* 8 667 136 B */
+int cmhsa_fp32_fwd_ws(const float *q, const float *k, const float *v, float *o,
+                      int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                      int64_t q_batch_stride, int64_t k_batch_stride, int64_t v_batch_stride, int64_t o_batch_stride,
+                      int batch, int seq_len, int num_heads, int head_dim,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* CMHSA_WORKSPACE_BYTES as a function (for bindings that cannot read the macro). */
+size_t cmhsa_workspace_bytes(void);
+
+/* Zeroes the workspace's counter block (the first 16 KiB) on `stream`; call once after allocating it. */
+int cmhsa_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+
+/* Workspace bytes the plan of this shape uses on the current device (0: the plan splits no query block). */
+size_t cmhsa_fp32_fwd_workspace_bytes(int batch, int seq_len, int num_heads);
+
+/* Diagnostics: writes a one-line description of the plan cmhsa_fp32_fwd (with_workspace = 0) or cmhsa_fp32_fwd_ws
+ * with a full-size workspace (1) uses for this shape on the current device into buf (NUL-terminated). */
+int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspace, char *buf, int buf_len);
+
 /* Convenience form of the reference's exact contract: 2-D (N, d_model) tensors, batch 1
  * (CMHSA.cu:476-478, :488-489, :500-512).  Equivalent to cmhsa_fp32_fwd(..., batch = 1). */
 int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,
@@ -76,11 +114,12 @@ int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,
  * Equivalent to cmhsa_fp32_fwd(qkv, qkv + d_model, qkv + 2*d_model, o, rs, rs, rs, o_row_stride, bs, bs,
  * bs, o_batch_stride, ...) with d_model = num_heads * head_dim; one pointer and one stride pair to
  * marshal instead of three.  Same status codes; a row stride below
- * 3*d_model is CMHSA_ERR_BAD_SHAPE. */
+ * 3*d_model is CMHSA_ERR_BAD_SHAPE.  workspace / workspace_bytes as in cmhsa_fp32_fwd_ws (NULL, 0 = none). */
 int cmhsa_fp32_fwd_packed_qkv(const float *qkv, float *o,
                               int64_t qkv_row_stride, int64_t o_row_stride,
                               int64_t qkv_batch_stride, int64_t o_batch_stride,
-                              int batch, int seq_len, int num_heads, int head_dim, void *stream);
+                              int batch, int seq_len, int num_heads, int head_dim,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 /* One-token ("decode") step over a KV cache -- opt-in, SURVEY.md section 8(f) row 4.  The reference keeps no
  * KV cache (README.md:12-13; sampler.py:14-19 re-runs the full forward per token); this entry point computes

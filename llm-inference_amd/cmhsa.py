@@ -5,6 +5,8 @@ arithmetic is entirely in the hand-written gfx950 kernels.  There is NO fallback
 is missing or no GPU is present, the calls raise.
 
   attention_fwd / attention_fwd_raw      cmhsa_fp32_fwd            full-sequence causal attention (the hot path)
+  attention_fwd(..., workspace=ws)       cmhsa_fp32_fwd_ws         the same with a device workspace (class Workspace): query
+                                                                   blocks may then be split across workgroups
   attention_fwd_packed_qkv               cmhsa_fp32_fwd_packed_qkv the same over one packed (.., T, 3*d_model) buffer
   decode_step                            cmhsa_fp32_decode_step    one-token step over a KV cache (opt-in)
   gelu_tanh_fwd                          gpt2_gelu_tanh_f32_fwd    fused tanh-GELU
@@ -28,6 +30,11 @@ EXPORTED_SYMBOLS = (
     "cmhsa_status_string",
     "cmhsa_version",
     "cmhsa_fp32_fwd",
+    "cmhsa_fp32_fwd_ws",
+    "cmhsa_workspace_bytes",
+    "cmhsa_workspace_init",
+    "cmhsa_fp32_fwd_workspace_bytes",
+    "cmhsa_plan_describe",
     "cmhsa_fp32_fwd_2d",
     "cmhsa_fp32_fwd_packed_qkv",
     "cmhsa_fp32_decode_step",
@@ -44,6 +51,7 @@ CMHSA_ERR_BAD_SHAPE = -2
 CMHSA_ERR_HEAD_DIM = -3
 CMHSA_ERR_ALIGNMENT = -4
 CMHSA_ERR_TOO_LARGE = -5
+CMHSA_ERR_WORKSPACE = -6
 
 _lib = None
 
@@ -64,17 +72,27 @@ def load_library() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `python llm-inference_amd/build.py` "
             "(there is no CPU or PyTorch fallback for the HIP attention path)")
     lib = ctypes.CDLL(LIB_PATH)
-    i64, i32, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+    i64, i32, vp, sz = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
     lib.cmhsa_status_string.restype = ctypes.c_char_p
     lib.cmhsa_status_string.argtypes = [i32]
     lib.cmhsa_version.restype = i32
     lib.cmhsa_version.argtypes = []
     lib.cmhsa_fp32_fwd.restype = i32
     lib.cmhsa_fp32_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp]
+    lib.cmhsa_fp32_fwd_ws.restype = i32
+    lib.cmhsa_fp32_fwd_ws.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp, sz, vp]
+    lib.cmhsa_workspace_bytes.restype = sz
+    lib.cmhsa_workspace_bytes.argtypes = []
+    lib.cmhsa_workspace_init.restype = i32
+    lib.cmhsa_workspace_init.argtypes = [vp, sz, vp]
+    lib.cmhsa_fp32_fwd_workspace_bytes.restype = sz
+    lib.cmhsa_fp32_fwd_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.cmhsa_plan_describe.restype = i32
+    lib.cmhsa_plan_describe.argtypes = [i32, i32, i32, i32, ctypes.c_char_p, i32]
     lib.cmhsa_fp32_fwd_2d.restype = i32
     lib.cmhsa_fp32_fwd_2d.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp]
     lib.cmhsa_fp32_fwd_packed_qkv.restype = i32
-    lib.cmhsa_fp32_fwd_packed_qkv.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, vp]
+    lib.cmhsa_fp32_fwd_packed_qkv.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, i32, vp, sz, vp]
     lib.cmhsa_fp32_decode_step.restype = i32
     lib.cmhsa_fp32_decode_step.argtypes = [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, vp]
     lib.cmhsa_decode_algorithmic_bytes.restype = ctypes.c_double
@@ -100,6 +118,40 @@ def algorithmic_flops(batch: int, seq_len: int, num_heads: int, head_dim: int = 
     return float(load_library().cmhsa_algorithmic_flops(batch, seq_len, num_heads, head_dim))
 
 
+def plan_description(batch: int, seq_len: int, num_heads: int, workspace_bytes: int = 0) -> str:
+    """One line on the plan the library uses for this shape on the current device (cmhsa_plan_describe)."""
+    buf = ctypes.create_string_buffer(512)
+    rc = load_library().cmhsa_plan_describe(batch, seq_len, num_heads, 1 if workspace_bytes > 0 else 0, buf, len(buf))
+    if rc != CMHSA_OK:
+        raise CmhsaError(rc, status_string(rc))
+    return buf.value.decode()
+
+
+class Workspace:
+    """Device workspace of cmhsa_fp32_fwd_ws: CMHSA_WORKSPACE_BYTES of torch-allocated (hipMalloc'd) device memory whose
+    counter block is zeroed once, on torch's current stream.  One per stream: calls that overlap in time on one GPU must
+    not share it."""
+
+    def __init__(self, device=None):
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        lib = load_library()
+        self.nbytes = int(lib.cmhsa_workspace_bytes())
+        self.buffer = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+        if self.buffer.data_ptr() % 256:
+            raise RuntimeError("allocator returned memory that is not 256-byte aligned")
+        self.ptr = ctypes.c_void_p(self.buffer.data_ptr())
+        self.device = device
+        self.reset()
+
+    def reset(self) -> None:
+        """Zero the counter block again (only needed after a launch that did not run to completion)."""
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = load_library().cmhsa_workspace_init(self.ptr, self.nbytes, ctypes.c_void_p(stream))
+        if rc != CMHSA_OK:
+            raise CmhsaError(rc, status_string(rc))
+
+
 def _check(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise ValueError(f"{name} must be a CUDA tensor")
@@ -121,11 +173,12 @@ def attention_fwd_raw(q_ptr: int, k_ptr: int, v_ptr: int, o_ptr: int,
 
 
 def attention_fwd(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: int,
-                  out: torch.Tensor | None = None) -> torch.Tensor:
+                  out: torch.Tensor | None = None, workspace: "Workspace | None" = None) -> torch.Tensor:
     """Causal multi-head self-attention forward through the C ABI, on torch's current stream.
 
     Q, K, V: (N, d_model) or (B, N, d_model) fp32 device tensors, last-dim stride 1, arbitrary
     row stride (multiple of 4).  Returns a new contiguous tensor unless `out` is given.
+    With `workspace` the call goes through cmhsa_fp32_fwd_ws (query blocks may be split across workgroups).
     """
     for t, n in ((Q, "Q"), (K, "K"), (V, "V")):
         _check(t, n)
@@ -143,14 +196,21 @@ def attention_fwd(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: 
     rs = [t.stride(-2) for t in (Q, K, V, out)]
     with torch.cuda.device(Q.device):
         stream = torch.cuda.current_stream(Q.device).cuda_stream
-        rc = attention_fwd_raw(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), rs, bs,
-                               B, N, num_heads, d_model // num_heads, stream)
+        if workspace is not None:
+            if workspace.device != Q.device:
+                raise ValueError("workspace is on another device")
+            rc = load_library().cmhsa_fp32_fwd_ws(
+                Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), *[int(x) for x in rs], *[int(x) for x in bs],
+                B, N, num_heads, d_model // num_heads, workspace.ptr, workspace.nbytes, ctypes.c_void_p(stream))
+        else:
+            rc = attention_fwd_raw(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), rs, bs,
+                                   B, N, num_heads, d_model // num_heads, stream)
     if rc != CMHSA_OK:
         raise CmhsaError(rc, status_string(rc))
     return out
 
 
-def attention_fwd_packed_qkv(QKV: torch.Tensor, num_heads: int) -> torch.Tensor:
+def attention_fwd_packed_qkv(QKV: torch.Tensor, num_heads: int, workspace: "Workspace | None" = None) -> torch.Tensor:
     """cmhsa_fp32_fwd_packed_qkv: QKV is the (N, 3*d_model) or (B, N, 3*d_model) output of the fused QKV linear layer
     (row = [Q | K | V], reference causal_self_attention.py:224-227); returns the (.., N, d_model) context."""
     _check(QKV, "QKV")
@@ -164,7 +224,8 @@ def attention_fwd_packed_qkv(QKV: torch.Tensor, num_heads: int) -> torch.Tensor:
         rc = load_library().cmhsa_fp32_fwd_packed_qkv(
             QKV.data_ptr(), out.data_ptr(), QKV.stride(-2), out.stride(-2),
             QKV.stride(0) if batched else 0, out.stride(0) if batched else 0,
-            QKV.shape[0] if batched else 1, QKV.shape[-2], num_heads, d_model // num_heads, ctypes.c_void_p(stream))
+            QKV.shape[0] if batched else 1, QKV.shape[-2], num_heads, d_model // num_heads,
+            workspace.ptr if workspace is not None else None, workspace.nbytes if workspace is not None else 0, ctypes.c_void_p(stream))
     if rc != CMHSA_OK:
         raise CmhsaError(rc, status_string(rc))
     return out

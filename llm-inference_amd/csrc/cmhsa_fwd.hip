@@ -28,10 +28,12 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 #include <type_traits>
@@ -44,6 +46,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kHeadDim = 64;            // CMHSA.cu:432
 constexpr int kQBlock = 32;             // query rows per workgroup (one MFMA N-tile)
@@ -54,12 +57,23 @@ constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
 constexpr int kMaxSeg = 4;                                // query blocks ("segments") one workgroup can hold (template kSegs: 2 or 4)
 constexpr int kMaxTableWgs = 64;                          // workgroups per (b,h) an explicit segment table can describe
+constexpr int kTableWords = 2 * kMaxSeg;                  // table words per workgroup: two per segment (see Params::seg_table)
+constexpr int kMaxParts = 4;                              // parts (on different workgroups) a query block's keys may be split into
+// One part's un-normalised result in the workspace: O image [8 pairs][64 lanes] float4 (the merge's native layout)
+// followed by (m, l) of the 32 queries.  33 whole 256-B lines.
+constexpr int kPartFloats = kUnitFloats + 64;
+constexpr size_t kWsCounterBytes = 16384;                 // head of the workspace: one arrival counter per split query block
+constexpr size_t kWsMaxParts = 1024;
+constexpr size_t kWsMaxBytes = kWsCounterBytes + kWsMaxParts * kPartFloats * 4;       // = CMHSA_WORKSPACE_BYTES (include/cmhsa.h)
+static_assert(kWsMaxBytes == CMHSA_WORKSPACE_BYTES, "include/cmhsa.h and the kernel disagree on the workspace size");
 // LDS: [kWaves][8 KiB] each wave's K unit (later its merge image) | [kSegs][8 KiB] pre-scaled query blocks |
-//      [kWaves][32 x (m, l)] softmax statistics for the merge
+//      [kWaves][32 x (m, l)] softmax statistics for the merge | [4] "this workgroup arrived last" flags (split plans)
 constexpr int lds_floats_q(int waves) { return waves * kUnitFloats; }
 constexpr int lds_floats_ml(int waves, int segs) { return (waves + segs) * kUnitFloats; }
-constexpr int lds_bytes(int waves, int segs) { return (lds_floats_ml(waves, segs) + waves * 64) * 4; }   // <= 98 KiB (8 waves), 65 KiB (4)
+constexpr int lds_floats_flags(int waves, int segs) { return lds_floats_ml(waves, segs) + waves * 64; }
+constexpr int lds_bytes(int waves, int segs) { return (lds_floats_flags(waves, segs) + 4) * 4; }   // <= 98 KiB (8 waves), 65 KiB (4)
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
+constexpr int kSc1 = 16;                                   // buffer load/store aux bits on gfx950: 16 = sc1 (agent-coherent: stores write through, loads bypass the CU's L1)
 constexpr float kRescaleSum = 1.8446744e19f;              // 2^64: a row sum of P above it triggers the rescale path
 
 // Diagnostic build only (-DCMHSA_STAMPS, tools/Makefile target cmhsa_bench_stamps): s_memtime stamps of
@@ -95,10 +109,20 @@ struct Params {
     int chain;                          // c: max units any wave processes (>= ceil(nqb / kWaves))
     int n_paired;                       // R: query blocks 1..R units long are paired n <-> R+1-n
     int n_alone;                        // nqb - R: the longest query blocks get a workgroup each
-    // explicit plan (use_table != 0; choose_plan()): workgroup j of every (b,h) holds the query blocks whose unit
-    // counts are the bytes of seg_table[j] (low byte first, 0 = none; a block with n units is block index n-1)
+    // explicit plan (use_table != 0; choose_plan()): workgroup j of every (b,h) holds up to four segments, two table
+    // words each (seg_table[j * 8 + 2 i], [.. + 1]; a segment with n = 0 is absent, present ones come first):
+    //   word 0: n (units of the query block = block index + 1) | first unit << 8 | unit count << 16 | wave mask << 24
+    //           -- the waves of the mask take the units [first, first + count) round-robin; count < n = the block's keys
+    //           are split across workgroups and this segment is one PART of it
+    //   word 1: 0 for a whole block, else  first part slot of the block | part index << 8 | parts << 12 | split id << 16
     int use_table;
-    unsigned seg_table[kMaxTableWgs];
+    // cross-workgroup split (table plans with parts only; null otherwise): a part's workgroup stores its un-normalised
+    // (O, m, l) to ws_parts[(bh * parts_per_bh + slot)] and counts itself in ws_counters[bh * splits_per_bh + split id];
+    // the workgroup that arrives last combines the parts in part order and writes O
+    float *ws_parts;
+    unsigned *ws_counters;
+    int parts_per_bh, splits_per_bh;
+    unsigned seg_table[kMaxTableWgs * kTableWords];
 };
 
 // Packing plan.  A query block with n units gets g(n) = ceil(n / c) waves, so that no wave runs more than c units
@@ -174,7 +198,10 @@ __device__ __forceinline__ int udiv_magic(int n, int d, unsigned magic) {
 }
 
 // kSegs = 2: the analytic plan (one block or a pair per workgroup); 4: an explicit table (Params::seg_table).
-template <int kWaves, int kSegs>
+// kAcquire: the last-arriving workgroup of a split query block runs an agent-scope acquire before it reads the other
+// parts (workspace in a __device__ array: the no-allocation entry point); without it every load of a part is an sc1 load
+// of sc1-stored, drained bytes in hipMalloc memory, one workgroup per CU (MI355X guide, visibility table row 1).
+template <int kWaves, int kSegs, bool kAcquire>
 __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -205,11 +232,20 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     const int bh = blockIdx.z * p.grid_x + blockIdx.x;
     const int j = blockIdx.y;
     // ---- workgroup j -> up to kSegs query blocks ("segments"), this wave -> (segment, local wave index) ----
-    int seg_n[kSegs];                           // units (= query block index + 1) of each segment; 0 = none
+    int seg_n[kSegs];                           // units (= query block index + 1) of each segment's query block; 0 = none
+    int seg_ulo[kSegs], seg_cnt[kSegs];          // the segment covers units [ulo, ulo + cnt) of it (the whole block: 0, n)
+    unsigned seg_mask[kSegs], seg_x[kSegs];      // waves working on it (bit w = wave w); table word 1 (0 = not a part)
     if (kSegs > 2) {                              // explicit plan (only this variant is launched with a table)
-        const unsigned e = p.seg_table[j];
+        const unsigned *e = p.seg_table + j * kTableWords;
 #pragma unroll
-        for (int i = 0; i < kSegs; ++i) seg_n[i] = (e >> (8 * i)) & 255;
+        for (int i = 0; i < kSegs; ++i) {
+            const unsigned w0 = e[2 * i];
+            seg_n[i] = w0 & 255;
+            seg_ulo[i] = (w0 >> 8) & 255;
+            seg_cnt[i] = (w0 >> 16) & 255;
+            seg_mask[i] = w0 >> 24;
+            seg_x[i] = e[2 * i + 1];
+        }
     } else {                                      // analytic plan: the longest blocks alone, the others paired n <-> R+1-n
 #pragma unroll
         for (int i = 0; i < kSegs; ++i) seg_n[i] = 0;
@@ -220,24 +256,32 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             seg_n[0] = p.n_paired - t;
             if (t + 1 != seg_n[0]) seg_n[1] = t + 1;   // (middle block of an odd count: alone with half the waves)
         }
-    }
-    int seg_lo[kSegs], seg_hi[kSegs];         // waves [seg_lo, seg_hi) work on segment i: ceil(n / c) of them
-    int n_units = 0, seg_w0 = wave, seg_waves = 1, seg = 0, n_seg = 0;   // defaults = idle wave: barriers and row work only
-    {
-        int w0 = 0;
+        int w0 = 0;                               // a block with n units gets ceil(n / c) consecutive waves
 #pragma unroll
         for (int i = 0; i < kSegs; ++i) {
             const int g = seg_n[i] ? udiv_magic(seg_n[i] + p.chain - 1, p.chain, p.chain_magic) : 0;
-            seg_lo[i] = w0;
-            seg_hi[i] = w0 + g;
-            if (wave >= w0 && wave < w0 + g) { seg = i; n_units = seg_n[i]; seg_w0 = w0; seg_waves = g; }
-            n_seg += seg_n[i] ? 1 : 0;
+            seg_mask[i] = ((1u << g) - 1u) << w0;
+            seg_ulo[i] = 0;
+            seg_cnt[i] = seg_n[i];
+            seg_x[i] = 0;
             w0 += g;
         }
     }
-    const int wloc = wave - seg_w0;
-    const bool active = n_units > 0;
-    const int qb = n_units - 1;      // causal early exit: units past the diagonal are never touched (CMHSA.cu:133-136)
+    // this wave -> (segment, index among the segment's waves); defaults = idle wave: barriers and row work only
+    int u_first = 0, u_end = 0, qb = -1, seg_waves = 1, seg = 0, n_seg = 0;
+    bool active = false;
+#pragma unroll
+    for (int i = 0; i < kSegs; ++i) {
+        if ((seg_mask[i] >> wave) & 1u) {
+            seg = i;
+            seg_waves = __builtin_popcount(seg_mask[i]);
+            u_first = seg_ulo[i] + __builtin_popcount(seg_mask[i] & ((1u << wave) - 1u));
+            u_end = seg_ulo[i] + seg_cnt[i];
+            qb = seg_n[i] - 1;                   // the diagonal unit; causal early exit: units past it are never touched (CMHSA.cu:133-136)
+            active = true;
+        }
+        n_seg += seg_n[i] ? 1 : 0;
+    }
     const int b = udiv_magic(bh, p.num_heads, p.heads_magic), h = bh - b * p.num_heads;
     const int N = p.seq_len;
 
@@ -261,7 +305,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     //      (Inactive waves and absent segments use zero-record descriptors: no memory touched, no branch.
     //      Giving the query blocks to waves 0-3 only, so that the barrier opens earlier, measured no faster.) ----
     f32x4 kst[8];                    // K staging registers (always one unit ahead of LDS)
-    load_unit(unit_rsrc(kg, p.k_rs, wloc * kKeyUnit, N, active), koff, kstep, kst);
+    load_unit(unit_rsrc(kg, p.k_rs, u_first * kKeyUnit, N, active), koff, kstep, kst);
     {
         constexpr int kQIters = kSegs * 8 / kWaves;
         f32x4 qst[kQIters];
@@ -332,7 +376,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             __amdgpu_buffer_rsrc_t vsrc0, ksrc1;
             if constexpr (kFirst) {
                 vsrc0 = unit_rsrc(vg, p.v_rs, u * kKeyUnit, N);
-                ksrc1 = unit_rsrc(kg, p.k_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < n_units);
+                ksrc1 = unit_rsrc(kg, p.k_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < u_end);
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -425,8 +469,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             //        steps 8-15 : K(u+2) global -> staging registers;  steps 13,14: first K(u+1) fragments ----
             //      Everything is unconditional (past the last unit the descriptors have zero records and the
             //      LDS unit receives zeros nobody reads), so the chain stays one basic block.
-            const __amdgpu_buffer_rsrc_t ksrc2 = unit_rsrc(kg, p.k_rs, (u + 2 * seg_waves) * kKeyUnit, N, u + 2 * seg_waves < n_units);
-            const __amdgpu_buffer_rsrc_t vsrc1 = unit_rsrc(vg, p.v_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < n_units);
+            const __amdgpu_buffer_rsrc_t ksrc2 = unit_rsrc(kg, p.k_rs, (u + 2 * seg_waves) * kKeyUnit, N, u + 2 * seg_waves < u_end);
+            const __amdgpu_buffer_rsrc_t vsrc1 = unit_rsrc(vg, p.v_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < u_end);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (r < 8) {
@@ -456,8 +500,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         };
 
         __builtin_amdgcn_s_setprio(2);
-        unit(wloc, std::true_type{});            // every active wave owns at least one unit (wloc < seg_waves <= n_units)
-        for (int u = wloc + seg_waves; u < n_units; u += seg_waves) unit(u, std::false_type{});
+        unit(u_first, std::true_type{});         // every active wave owns at least one unit (a segment has no more waves than units)
+        for (int u = u_first + seg_waves; u < u_end; u += seg_waves) unit(u, std::false_type{});
         l_run = xhalf_sum(l_run);
     }
 #ifdef CMHSA_STAMPS
@@ -513,7 +557,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 float m_tot = -INFINITY;
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) {
-                    const unsigned mine = (w >= seg_lo[sg] && w < seg_hi[sg]) ? 0xffffffffu : 0u;
+                    const unsigned mine = 0u - ((seg_mask[sg] >> w) & 1u);
                     mw[w] = __uint_as_float((__float_as_uint(mv[w]) & mine) | (~mine & 0xff800000u));   // -inf when not mine
                     m_tot = fmaxf(m_tot, mw[w]);
                 }
@@ -525,9 +569,95 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                     l_tot += lv[w] * f;
                     acc += __builtin_bit_cast(f32x4, ov[w]) * f;
                 }
-                acc *= 1.0f / l_tot;
-                const int row = (seg_n[sg] - 1) * kQBlock + l31;
-                if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
+                if (kSegs > 2 && seg_x[sg] != 0) {                               // wave-uniform
+                    // ONE PART of a query block whose keys are split across workgroups: the un-normalised (O, m, l)
+                    // goes to the workspace in the layout of the LDS images (a wave's store covers eight whole 128-B
+                    // lines), write-through (sc1), so that no release fence is needed before the arrival counter
+                    const int slot = (int)(seg_x[sg] & 255u) + (int)((seg_x[sg] >> 8) & 15u);
+                    float *img = p.ws_parts + ((int64_t)bh * p.parts_per_bh + slot) * kPartFloats;
+                    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(img, 0, kPartFloats * 4, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), prs, (pi * 64 + lane) * 16, 0, kSc1);
+                    if (pi == 0 && lane < 32)
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{m_tot, l_tot}), prs, kUnitFloats * 4 + lane * 8, 0, kSc1);
+                } else {
+                    acc *= 1.0f / l_tot;
+                    const int row = (seg_n[sg] - 1) * kQBlock + l31;
+                    if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
+                }
+            }
+        }
+        // ---- query blocks split across workgroups: count this workgroup in; the one that arrives LAST combines.
+        //      No workgroup ever waits for another (no spin, no residency assumption): every part's workgroup stores
+        //      its partial (sc1, above), every storing wave drains its stores, the workgroup meets at a barrier, ONE
+        //      lane per part adds to the block's arrival counter (agent scope, returning) and the workgroup whose add
+        //      returns parts-1 reads all parts back (sc1 loads straight to registers; behind an agent-scope acquire
+        //      when kAcquire) and combines them in PART ORDER, whoever it is -- the result bits do not depend on the
+        //      arrival order.  The last arriver also puts the counter back to 0 for the next launch. ----
+        if constexpr (kSegs > 2) {
+            unsigned any_part = 0;
+#pragma unroll
+            for (int sg = 0; sg < kSegs; ++sg) any_part |= seg_x[sg];
+            if (any_part) {                                                      // workgroup-uniform
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // EVERY storing wave: its sc1 stores have left
+                __syncthreads();
+                unsigned *flags = reinterpret_cast<unsigned *>(lds + lds_floats_flags(kWaves, kSegs));
+                if (threadIdx.x < kSegs) {
+                    const int t = threadIdx.x;
+                    const unsigned x = t == 0 ? seg_x[0] : t == 1 ? seg_x[1] : t == 2 ? seg_x[2] : seg_x[3];
+                    unsigned last = 0;
+                    if (x) {
+                        unsigned *cnt = p.ws_counters + (int64_t)bh * p.splits_per_bh + (x >> 16);
+                        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        last = old + 1u == ((x >> 12) & 15u) ? 1u : 0u;
+                        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    flags[t] = last;
+                }
+                if (kAcquire && wave == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+#pragma unroll
+                for (int sg = 0; sg < kSegs; ++sg) {
+                    if (seg_x[sg] == 0) continue;                                // wave-uniform
+                    if (__builtin_amdgcn_readfirstlane(flags[sg]) == 0) continue;    // another workgroup finishes this block
+                    const int first = (int)(seg_x[sg] & 255u), nparts = (int)((seg_x[sg] >> 12) & 15u);
+                    const float *base = p.ws_parts + ((int64_t)bh * p.parts_per_bh + first) * kPartFloats;
+#pragma unroll
+                    for (int pc = 0; pc < 8 / kWaves; ++pc) {
+                        const int pi = wave + pc * kWaves;
+                        float pm[kMaxParts], pl[kMaxParts];
+                        f32x4 po[kMaxParts];
+#pragma unroll
+                        for (int q = 0; q < kMaxParts; ++q) {
+                            pm[q] = -INFINITY; pl[q] = 0.f; po[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (q < nparts) {                                    // wave-uniform
+                                const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                                    const_cast<float *>(base + (int64_t)q * kPartFloats), 0, kPartFloats * 4, 0x00020000);
+                                const f32x2 ml = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prs, kUnitFloats * 4 + l31 * 8, 0, kSc1));
+                                pm[q] = ml[0];
+                                pl[q] = ml[1];
+                                po[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, (pi * 64 + lane) * 16, 0, kSc1));
+                            }
+                        }
+                        float m_tot = pm[0];
+#pragma unroll
+                        for (int q = 1; q < kMaxParts; ++q) m_tot = fmaxf(m_tot, pm[q]);
+                        float l_tot = 0.f;
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int q = 0; q < kMaxParts; ++q) {
+                            const float f = __builtin_amdgcn_exp2f(pm[q] - m_tot);  // 0 for absent parts (m = -inf)
+                            l_tot += pl[q] * f;
+                            acc += po[q] * f;
+                        }
+                        acc *= 1.0f / l_tot;
+                        const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);
+                        const int row = (seg_n[sg] - 1) * kQBlock + l31;
+                        if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
+                    }
+                }
             }
         }
     }
@@ -537,16 +667,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 #endif
 }
 
-std::atomic<int> g_attr_set[4][64];  // per variant and device: dynamic-LDS limit raised once, not per call
+std::atomic<int> g_attr_set[5][64];  // per variant and device: dynamic-LDS limit raised once, not per call
 
-template <int kWaves, int kSegs>
+template <int kWaves, int kSegs, bool kAcquire>
 hipError_t launch(const Params &p, dim3 grid, void *stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[(kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
+    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kAcquire ? 4 : (kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
     if (!flag || !flag->load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs, kAcquire>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kWaves, kSegs));
         if (e != hipSuccess) return e;
         if (flag) flag->store(1, std::memory_order_release);
@@ -554,29 +684,43 @@ hipError_t launch(const Params &p, dim3 grid, void *stream) {
     // hipLaunchKernel returns this launch's own status: an error left behind by an unrelated earlier HIP call on
     // this thread is neither reported as ours nor cleared (hipGetLastError would do both)
     void *args[] = {const_cast<Params *>(&p)};
-    return hipLaunchKernel(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs>), grid, dim3(kWaves * 64), args,
+    return hipLaunchKernel(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs, kAcquire>), grid, dim3(kWaves * 64), args,
                            lds_bytes(kWaves, kSegs), static_cast<hipStream_t>(stream));
 }
 
 // ---- plan selection (host) ---------------------------------------------------------------------------------------
-// A plan = (waves per workgroup W, chain cap c, which query blocks each workgroup of a (b,h) holds).  Two families:
+// A plan says which query blocks (or parts of them) each workgroup of a (b,h) holds and which of its waves work on
+// each.  Three families:
 //   analytic  pack_plan(): a block alone or a pair n <-> R+1-n; decoded in the kernel from three integers; any size;
-//   table     up to 4 blocks per workgroup, packed greedily (longest block first into the feasible workgroup with
-//             the fewest units), handed to the kernel as Params::seg_table; nqb <= 255 and <= 64 workgroups per (b,h).
-// Grids that fit the chip in ONE round are where the choice matters (measured, tools/sweep_plans.sh: H = 16, 20 at
-// B=1, T=1024 gain 30 % / 10 %): among the single-round candidates the cheapest by
-//     cycles = kFixed + (units on the busiest SIMD of the longest workgroup) * kUnit      (8 k + n * 5 k, measured)
+//   chain     table plan: every block gets ceil(n / c) consecutive waves, blocks packed greedily (longest first into
+//             the feasible workgroup with the fewest units), up to 4 per workgroup;
+//   packed    table plan from pack_blocks(): a cap L on the units any SIMD runs (waves w and w+4 of an 8-wave workgroup
+//             share one), blocks placed wave by wave under that cap; with a workspace, a block may be cut into two
+//             PARTS held by different workgroups (its keys split in two ranges, merged through the workspace by the
+//             workgroup that finishes last) -- the only way to put fewer units on a SIMD than the longest block has
+//             per SIMD of one CU, and to use every CU when the blocks do not divide evenly.
+// Table plans describe at most 64 workgroups per (b,h) and blocks of at most 255 units.
+// Grids that fit the chip in ONE round are where the choice matters (measured, tools/sweep_plans.sh): among the
+// single-round candidates the cheapest by
+//     cycles = kFixed + (units on the busiest SIMD) * kUnit  [+ kHandoff in a workgroup that holds a part]
 // wins; an 8-wave workgroup owns its CU (two of its waves per SIMD), two 4-wave workgroups share one.  Grids of
 // several rounds run within +-3 % of each other under every plan tried, so they keep the analytic plan with 4-wave
 // workgroups at the smallest c (two co-resident workgroups hide each other's prologue and merge).
+constexpr double kFixedCycles = 8000.0, kUnitCycles = 5000.0, kHandoffCycles = 5000.0;
+
 struct Plan {
-    PackPlan pp;
+    PackPlan pp;                                 // waves, and for analytic / chain plans the chain cap
     bool use_table = false;
     int n_wgs = 0;                               // workgroups per (b,h)
+    int parts_per_bh = 0, splits_per_bh = 0;     // > 0: some blocks are split across workgroups (needs a workspace)
+    int simd_cap = 0;                            // packed plans: L
     bool single_round = false;                   // the whole grid is resident at once
-    unsigned char segs[kMaxTableWgs][kMaxSeg];   // table plans: unit counts per workgroup, 0 = none
     double cycles = 0.0;
+    const char *family = "analytic";
+    unsigned table[kMaxTableWgs * kTableWords];  // table plans: Params::seg_table
 };
+
+inline unsigned seg_word0(int n, int lo, int cnt, unsigned mask) { return (unsigned)n | ((unsigned)lo << 8) | ((unsigned)cnt << 16) | (mask << 24); }
 
 // units on the busiest SIMD of a workgroup holding blocks n[0..k): block i gets ceil(n_i/c) consecutive waves, its
 // units go round-robin over them; waves w and w+4 share a SIMD
@@ -593,21 +737,20 @@ int busiest_simd(const int *n, int k, int c, int waves) {
 }
 
 void price(Plan &pl, const int (*wg_blocks)[kMaxSeg], int n_wgs, int64_t bh, int cus) {
-    constexpr double kFixed = 8000.0, kUnit = 5000.0;
     const int waves = pl.pp.waves;
     const int64_t wgs = bh * n_wgs;
     const bool shared = waves == 4 && wgs > cus;                    // a second 4-wave workgroup on the same CU
     double longest = 0.0;
     for (int j = 0; j < n_wgs; ++j) {
         const int l = busiest_simd(wg_blocks[j], kMaxSeg, pl.pp.chain, waves);
-        longest = fmax(longest, kFixed + (shared ? 2.0 : 1.0) * l * kUnit);
+        longest = fmax(longest, kFixedCycles + (shared ? 2.0 : 1.0) * l * kUnitCycles);
     }
     pl.n_wgs = n_wgs;
     pl.single_round = wgs <= (int64_t)cus * (waves == 8 ? 1 : 2);
     pl.cycles = longest;                 // meaningful for single-round grids only, the only ones compared
 }
 
-bool table_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
+bool chain_table_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
     if (nqb > 255) return false;
     int blocks[kMaxTableWgs][kMaxSeg] = {}, units[kMaxTableWgs] = {}, free_waves[kMaxTableWgs], nseg[kMaxTableWgs] = {};
     int n_wgs = 0;
@@ -637,8 +780,16 @@ bool table_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
     pl.pp = pack_plan(nqb, waves, c);
     pl.pp.wgs_per_bh = n_wgs;
     pl.use_table = true;
-    for (int j = 0; j < n_wgs; ++j)
-        for (int t = 0; t < kMaxSeg; ++t) pl.segs[j][t] = (unsigned char)blocks[j][t];
+    pl.family = "chain table";
+    for (int j = 0; j < n_wgs; ++j) {
+        int w0 = 0;
+        for (int t = 0; t < kMaxSeg; ++t) {
+            const int n = blocks[j][t], g = n ? (n + c - 1) / c : 0;
+            pl.table[j * kTableWords + 2 * t] = n ? seg_word0(n, 0, n, ((1u << g) - 1u) << w0) : 0u;
+            pl.table[j * kTableWords + 2 * t + 1] = 0u;
+            w0 += g;
+        }
+    }
     price(pl, blocks, n_wgs, bh, cus);
     return true;
 }
@@ -646,6 +797,7 @@ bool table_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
 void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
     pl.pp = pack_plan(nqb, waves, c);
     pl.use_table = false;
+    pl.family = "analytic";
     // priced from its closed form: the alone blocks nqb, nqb-1, ..., then the pairs (R - t, t + 1)
     std::vector<int> flat((size_t)pl.pp.wgs_per_bh * kMaxSeg, 0);
     int (*blocks)[kMaxSeg] = reinterpret_cast<int (*)[kMaxSeg]>(flat.data());
@@ -656,9 +808,180 @@ void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
     price(pl, blocks, pl.pp.wgs_per_bh, bh, cus);
 }
 
-// Experiments only (tools/ and the forced-plan tests build the library with -DCMHSA_PLAN_ENV): CMHSA_WAVES=4|8,
-// CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force a plan, CMHSA_VERBOSE prints the choice.  The shipped library reads no
-// environment variable.
+// ---- packed plans: 8-wave workgroups, one per CU -------------------------------------------------------------------
+// Work items = whole query blocks, or the two parts of a block cut at a unit boundary.  Items go, longest first (with a
+// little seeded jitter, so that a failed attempt is followed by a different one), into the fullest workgroup that
+// takes them, else into a new one.  "Takes" = there is a set of g free wave slots such that, with the item's units
+// dealt round-robin to those waves in ascending wave order (what the kernel does), no SIMD (slots s and s+4) runs more
+// than `cap` units: cap = L, or L-1 in a workgroup that holds a part -- the hand-off through the workspace costs about
+// a unit of time.  g runs from ceil(cnt / ceil(cap/2)) (prefer two waves per SIMD over one long chain) upwards.
+struct PackItem { int n, lo, cnt, split; double key; };          // split: -1 = whole block, else index of the split block
+struct PackWg {
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned used = 0;                           // wave slots taken
+    int nseg = 0, total = 0;
+    bool partial = false;
+    int seg_n[kMaxSeg], seg_lo[kMaxSeg], seg_cnt[kMaxSeg], seg_split[kMaxSeg];
+    unsigned seg_mask[kMaxSeg];
+};
+
+struct Rng {                                     // xorshift64*: deterministic, seeded per shape
+    uint64_t s;
+    double next() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return (double)((s * 2685821657736338717ull) >> 11) / 9007199254740992.0; }
+};
+
+// best set of g free slots of `wg` for an item of cnt units under `cap`; 0 if none
+unsigned best_slots(const PackWg &wg, int cnt, int g, int cap) {
+    unsigned best = 0;
+    int best_score = 1 << 30;
+    const unsigned free_mask = ~wg.used & 0xffu;
+    for (unsigned m = 1; m < 256; ++m) {
+        if ((m & free_mask) != m || __builtin_popcount(m) != g) continue;
+        int load[8], i = 0, score = 0;
+        bool ok = true;
+        for (int w = 0; w < 8; ++w) {
+            load[w] = wg.load[w];
+            if ((m >> w) & 1u) { load[w] = cnt / g + (i < cnt % g ? 1 : 0); ++i; }
+        }
+        for (int sidx = 0; sidx < 4 && ok; ++sidx) {
+            const int sum = load[sidx] + load[sidx + 4];
+            if (sum > cap) ok = false;
+            const bool touched = ((m >> sidx) | (m >> (sidx + 4))) & 1u;
+            const bool full_pair = (((wg.used | m) >> sidx) & 1u) && (((wg.used | m) >> (sidx + 4)) & 1u);
+            if (touched) score += full_pair ? (cap - sum) : (cap - sum) + cap;     // prefer completing a SIMD tightly
+        }
+        if (ok && score < best_score) { best_score = score; best = m; }
+    }
+    return best;
+}
+
+bool pack_attempt(int nqb, int L, bool allow_split, double psplit, Rng &rng, int g_max, std::vector<PackWg> &wgs, int &n_splits) {
+    const int Lp = L - 1;
+    std::vector<PackItem> items;
+    n_splits = 0;
+    for (int n = nqb; n >= 1; --n) {
+        const bool must = n > 4 * L;
+        if (must && (!allow_split || Lp < 1)) return false;
+        if (must || (allow_split && Lp >= 1 && n > 8 && rng.next() < psplit)) {
+            const int lo_cut = max(1, n - 4 * Lp), hi_cut = min(n - 1, 4 * Lp);
+            if (lo_cut > hi_cut) return false;                       // would need more than two parts
+            const int cut = lo_cut + (int)(rng.next() * (hi_cut - lo_cut + 1));
+            items.push_back(PackItem{n, 0, cut, n_splits, 0.0});
+            items.push_back(PackItem{n, cut, n - cut, n_splits, 0.0});
+            ++n_splits;
+        } else {
+            items.push_back(PackItem{n, 0, n, -1, 0.0});
+        }
+    }
+    if (n_splits > 127) return false;
+    for (PackItem &it : items) it.key = -(double)it.cnt + 3.0 * rng.next();
+    std::stable_sort(items.begin(), items.end(), [](const PackItem &a, const PackItem &b) { return a.key < b.key; });
+    wgs.clear();
+    for (const PackItem &it : items) {
+        const bool part = it.split >= 0;
+        // candidates: existing workgroups, fullest first, then a new one
+        std::vector<int> order(wgs.size());
+        for (size_t j = 0; j < order.size(); ++j) order[j] = (int)j;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wgs[a].total > wgs[b].total; });
+        order.push_back(-1);
+        bool placed = false;
+        for (int j : order) {
+            PackWg fresh;
+            PackWg &wg = j < 0 ? fresh : wgs[j];
+            if (wg.nseg >= kMaxSeg) continue;
+            const int cap = (wg.partial || part) ? Lp : L;
+            if (part && !wg.partial) {
+                bool fits = true;
+                for (int sidx = 0; sidx < 4; ++sidx) fits &= wg.load[sidx] + wg.load[sidx + 4] <= Lp;
+                if (!fits) continue;
+            }
+            bool same_block = false;
+            for (int t = 0; t < wg.nseg; ++t) same_block |= wg.seg_n[t] == it.n;
+            if (same_block) continue;                                   // both parts of a block in one workgroup: pointless
+            // wave counts to try: from two waves per SIMD's worth upwards, then -- longer chains, one wave on a SIMD --
+            // downwards to the fewest waves the cap allows
+            const int wcap = (cap + 1) / 2, free_slots = 8 - __builtin_popcount(wg.used);
+            const int g_pref = (it.cnt + wcap - 1) / wcap, g_abs = (it.cnt + cap - 1) / cap, g_hi = min(free_slots, it.cnt);
+            for (int step = 0; step < 16; ++step) {
+                const int g = step < 8 ? g_pref + step : g_pref - 1 - (step - 8);
+                if (g > g_hi || g < g_abs || g < 1) continue;
+                const unsigned m = best_slots(wg, it.cnt, g, cap);
+                if (!m) continue;
+                int i = 0;
+                for (int w = 0; w < 8; ++w)
+                    if ((m >> w) & 1u) { wg.load[w] = it.cnt / g + (i < it.cnt % g ? 1 : 0); ++i; }
+                wg.used |= m;
+                wg.seg_n[wg.nseg] = it.n; wg.seg_lo[wg.nseg] = it.lo; wg.seg_cnt[wg.nseg] = it.cnt;
+                wg.seg_split[wg.nseg] = it.split; wg.seg_mask[wg.nseg] = m;
+                ++wg.nseg;
+                wg.total += it.cnt;
+                wg.partial |= part;
+                placed = true;
+                break;
+            }
+            if (placed) {
+                if (j < 0) {
+                    if ((int)wgs.size() == g_max) return false;
+                    wgs.push_back(fresh);
+                }
+                break;
+            }
+        }
+        if (!placed) return false;
+    }
+    return true;
+}
+
+bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus) {
+    if (nqb > 255 || bh > cus) return false;
+    const int g_max = (int)min((int64_t)kMaxTableWgs, (int64_t)cus / bh);
+    Rng rng{0x9E3779B97F4A7C15ull ^ ((uint64_t)nqb << 32) ^ ((uint64_t)L << 16) ^ (uint64_t)g_max ^ (allow_split ? 0x5555ull : 0ull)};
+    std::vector<PackWg> wgs;
+    int n_splits = 0;
+    bool ok = false;
+    // whole blocks first (and parts only where a block cannot fit); then a little optional splitting
+    const int tries = allow_split ? 24 : 6;
+    for (int t = 0; t < tries && !ok; ++t) {
+        const double psplit = !allow_split || t < 6 ? 0.0 : 0.04 * (1 + (t - 6) / 6);
+        ok = pack_attempt(nqb, L, allow_split, psplit, rng, g_max, wgs, n_splits);
+    }
+    if (!ok) return false;
+    if (bh * n_splits * 2 > (int64_t)kWsMaxParts || bh * n_splits * 4 > (int64_t)kWsCounterBytes) return false;
+    std::stable_sort(wgs.begin(), wgs.end(), [](const PackWg &a, const PackWg &b) { return a.total > b.total; });   // heaviest first
+    pl.pp = pack_plan(nqb, 8, (L + 1) / 2);
+    pl.pp.wgs_per_bh = (int)wgs.size();
+    pl.use_table = true;
+    pl.family = n_splits ? "packed table, blocks split across workgroups" : "packed table";
+    pl.n_wgs = (int)wgs.size();
+    pl.simd_cap = L;
+    pl.splits_per_bh = n_splits;
+    pl.parts_per_bh = 2 * n_splits;
+    pl.single_round = true;
+    double longest = 0.0;
+    for (int j = 0; j < pl.n_wgs; ++j) {
+        const PackWg &wg = wgs[j];
+        int busiest = 0;
+        for (int sidx = 0; sidx < 4; ++sidx) busiest = max(busiest, wg.load[sidx] + wg.load[sidx + 4]);
+        longest = fmax(longest, kFixedCycles + busiest * kUnitCycles + (wg.partial ? kHandoffCycles : 0.0));
+        for (int t = 0; t < kMaxSeg; ++t) {
+            unsigned w0 = 0, w1 = 0;
+            if (t < wg.nseg) {
+                w0 = seg_word0(wg.seg_n[t], wg.seg_lo[t], wg.seg_cnt[t], wg.seg_mask[t]);
+                if (wg.seg_split[t] >= 0)        // first slot | part index << 8 | parts << 12 | split id << 16
+                    w1 = (unsigned)(2 * wg.seg_split[t]) | ((wg.seg_lo[t] ? 1u : 0u) << 8) | (2u << 12) | ((unsigned)wg.seg_split[t] << 16);
+            }
+            pl.table[j * kTableWords + 2 * t] = w0;
+            pl.table[j * kTableWords + 2 * t + 1] = w1;
+        }
+    }
+    pl.cycles = longest;
+    return true;
+}
+
+// Experiments only (tests/helpers/libcmhsa_hip_planenv.so and tools/ build the library with -DCMHSA_PLAN_ENV):
+// CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force an analytic / chain plan, CMHSA_PACKED=L forces a packed plan
+// with SIMD cap L (CMHSA_SPLIT=0|1: without / with blocks split across workgroups), CMHSA_VERBOSE prints the choice.
+// The shipped library reads no environment variable.
 #ifdef CMHSA_PLAN_ENV
 int env_int(const char *name, int fallback) { const char *e = getenv(name); return e ? atoi(e) : fallback; }
 #else
@@ -675,13 +998,16 @@ int device_cu_count(int dev) {
     return n;
 }
 
-Plan choose_plan(int64_t bh, int nqb, int cus) {
+Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
     static const int forced_waves = env_int("CMHSA_WAVES", 0);
     static const int forced_chain = env_int("CMHSA_CHAIN", 0);
     static const int forced_table = env_int("CMHSA_TABLE", -1);
+    static const int forced_packed = env_int("CMHSA_PACKED", 0);
+    static const int forced_split = env_int("CMHSA_SPLIT", -1);
     Plan best;
     bool have = false;
-    for (int waves = 8; waves >= 4; waves -= 4) {
+    const bool forced_old = (forced_waves != 0) | (forced_chain != 0) | (forced_table >= 0);
+    for (int waves = 8; waves >= 4 && !forced_packed; waves -= 4) {
         if (forced_waves && forced_waves != waves) continue;
         const int c_min = (nqb + waves - 1) / waves;
         // nothing changes any more once every block fits in one wave; nqb > 4096: only the smallest c (pricing is O(nqb))
@@ -689,42 +1015,62 @@ Plan choose_plan(int64_t bh, int nqb, int cus) {
         for (int c = forced_chain ? c_max : c_min; c <= c_max; ++c) {
             for (int table = 0; table <= 1; ++table) {
                 if (forced_table >= 0 && forced_table != table) continue;
-                const bool forced = (forced_waves != 0) | (forced_chain != 0) | (forced_table >= 0);
                 // only single-round grids are compared: skip the others before the O(nqb) pricing
-                if (!table && !forced && bh * pack_plan(nqb, waves, c).wgs_per_bh > (int64_t)cus * (waves == 8 ? 1 : 2)) continue;
+                if (!table && !forced_old && bh * pack_plan(nqb, waves, c).wgs_per_bh > (int64_t)cus * (waves == 8 ? 1 : 2)) continue;
                 Plan pl;
-                if (table) { if (!table_plan(pl, nqb, waves, c, bh, cus)) continue; }
+                if (table) { if (!chain_table_plan(pl, nqb, waves, c, bh, cus)) continue; }
                 else analytic_plan(pl, nqb, waves, c, bh, cus);
-                if (!pl.single_round && !forced) continue;
+                if (!pl.single_round && !forced_old) continue;
                 // ties: keep the earlier candidate (8 waves before 4, small c before large, analytic before table)
                 if (!have || pl.cycles < best.cycles * 0.98) { best = pl; have = true; }
             }
         }
     }
+    // packed plans: the smallest SIMD caps that could hold the work, without and (given a workspace) with split blocks
+    if (!forced_old && nqb <= 255 && bh <= cus) {
+        const int g_max = (int)min((int64_t)kMaxTableWgs, (int64_t)cus / bh);
+        const int64_t total = (int64_t)nqb * (nqb + 1) / 2;
+        const int l_min = forced_packed ? forced_packed : (int)max((int64_t)1, (total + 4 * g_max - 1) / (4 * g_max));
+        const int l_max = forced_packed ? forced_packed : l_min + 3;
+        for (int L = l_min; L <= l_max; ++L) {
+            for (int split = 0; split <= (allow_split ? 1 : 0); ++split) {
+                if (forced_split >= 0 && forced_split != split && (allow_split || forced_split == 0)) continue;
+                Plan pl;
+                if (!packed_plan(pl, nqb, L, split != 0, bh, cus)) continue;
+                if (split && !pl.splits_per_bh) continue;            // the same plan as split = 0
+                if (!have || pl.cycles < best.cycles * 0.98) { best = pl; have = true; }
+            }
+        }
+    }
     if (!have) {                                     // several rounds (or an impossible forced combination)
+        best = Plan();
         best.pp = pack_plan(nqb, 4);
         best.use_table = false;
         best.n_wgs = best.pp.wgs_per_bh;
     }
     static const bool verbose = env_int("CMHSA_VERBOSE", 0) != 0;
     if (verbose)
-        fprintf(stderr, "cmhsa plan: bh=%lld nqb=%d cus=%d -> waves=%d chain=%d %s wgs/bh=%d est=%.0f cycles\n", (long long)bh, nqb, cus,
-                best.pp.waves, best.pp.chain, best.use_table ? "table" : "analytic", best.n_wgs, best.cycles);
+        fprintf(stderr, "cmhsa plan: bh=%lld nqb=%d cus=%d -> %s, waves=%d chain=%d simd cap=%d wgs/bh=%d split blocks/bh=%d est=%.0f cycles\n",
+                (long long)bh, nqb, cus, best.family, best.pp.waves, best.pp.chain, best.simd_cap, best.n_wgs, best.splits_per_bh, best.cycles);
     return best;
 }
 
 // choose_plan() prices dozens of candidates; calls repeat the same few shapes, so the result is memoised per
-// (shape, CU count of the device the call runs on)
-Plan cached_plan(int64_t bh, int nqb, int cus) {
-    struct Entry { int64_t bh; int nqb, cus; Plan plan; };
+// (shape, CU count of the device the call runs on, workspace available or not)
+Plan cached_plan(int64_t bh, int nqb, int cus, bool allow_split) {
+    struct Entry { int64_t bh; int nqb, cus; bool allow_split; Plan plan; };
     static std::mutex mu;
     static std::vector<Entry> cache;
     std::lock_guard<std::mutex> lock(mu);
     for (const Entry &e : cache)
-        if (e.bh == bh && e.nqb == nqb && e.cus == cus) return e.plan;
+        if (e.bh == bh && e.nqb == nqb && e.cus == cus && e.allow_split == allow_split) return e.plan;
     if (cache.size() >= 256) cache.clear();
-    cache.push_back(Entry{bh, nqb, cus, choose_plan(bh, nqb, cus)});
+    cache.push_back(Entry{bh, nqb, cus, allow_split, choose_plan(bh, nqb, cus, allow_split)});
     return cache.back().plan;                        // by value: the entry may be gone once the lock is released
+}
+
+size_t plan_workspace_bytes(const Plan &pl, int64_t bh) {
+    return pl.parts_per_bh ? kWsCounterBytes + (size_t)bh * pl.parts_per_bh * kPartFloats * 4 : 0;
 }
 
 // clock probe (cmhsa_probe_shader_clock): 4 independent MFMA chains per wave keep the matrix pipe saturated
@@ -773,6 +1119,7 @@ const char *cmhsa_status_string(int status) {
         case CMHSA_ERR_HEAD_DIM: return "Head dimension must be 64.";
         case CMHSA_ERR_ALIGNMENT: return "pointers must be 16-byte aligned and row/batch strides multiples of 4 for float4 loads to work";
         case CMHSA_ERR_TOO_LARGE: return "problem too large for 32-bit tile indexing";
+        case CMHSA_ERR_WORKSPACE: return "workspace too small for this shape's plan";
         default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown cmhsa status";
     }
 }
@@ -795,33 +1142,58 @@ double cmhsa_algorithmic_flops(int batch, int seq_len, int num_heads, int head_d
     return 2.0 * batch * num_heads * head_dim * (double)seq_len * ((double)seq_len + 1.0);
 }
 
-int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
-                   int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
-                   int64_t q_batch_stride, int64_t k_batch_stride, int64_t v_batch_stride, int64_t o_batch_stride,
-                   int batch, int seq_len, int num_heads, int head_dim, void *stream) {
+}  // extern "C"
+
+namespace {
+
+// Validation shared by every forward entry point; on success the shape in blocks and (b,h)s.
+int check_forward_args(const float *q, const float *k, const float *v, float *o,
+                       int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
+                       int64_t &q_bs, int64_t &k_bs, int64_t &v_bs, int64_t &o_bs,
+                       int batch, int seq_len, int num_heads, int head_dim, int64_t &nqb, int64_t &bh, bool &empty) {
+    empty = false;
     if (batch < 0 || seq_len < 0 || num_heads <= 0) return CMHSA_ERR_BAD_SHAPE;
     if (head_dim != kHeadDim) return CMHSA_ERR_HEAD_DIM;
-    if (batch == 0 || seq_len == 0) return CMHSA_OK;
+    if (batch == 0 || seq_len == 0) { empty = true; return CMHSA_OK; }
     if (!q || !k || !v || !o) return CMHSA_ERR_NULL_POINTER;
-    if (batch == 1) q_batch_stride = k_batch_stride = v_batch_stride = o_batch_stride = 0;
+    if (batch == 1) q_bs = k_bs = v_bs = o_bs = 0;
     const uintptr_t ptr_bits = (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o;
-    const int64_t stride_bits = q_row_stride | k_row_stride | v_row_stride | o_row_stride |
-                                q_batch_stride | k_batch_stride | v_batch_stride | o_batch_stride;
+    const int64_t stride_bits = q_rs | k_rs | v_rs | o_rs | q_bs | k_bs | v_bs | o_bs;
     if ((ptr_bits & 15) || (stride_bits & 3)) return CMHSA_ERR_ALIGNMENT;
     if (stride_bits < 0) return CMHSA_ERR_BAD_SHAPE;             // a negative stride (sign bit set in the OR of all)
-
-    const int64_t nqb = ((int64_t)seq_len + kQBlock - 1) / kQBlock;
-    const int64_t bh = (int64_t)batch * num_heads;
+    nqb = ((int64_t)seq_len + kQBlock - 1) / kQBlock;
+    bh = (int64_t)batch * num_heads;
     // 32-bit row arithmetic in the kernel: the software pipeline forms row numbers up to (nqb + 2 * 8 waves) * 32 and
     // multiplies none of them by a stride in 32 bits (row offsets are 64-bit), so the bound is on the row number itself
     if ((nqb + 16) * kKeyUnit > 0x7fffffffLL || bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
     // 32-bit byte offsets inside a 32-row unit (buffer loads): 32 rows * row_stride * 4 B must fit
-    const int64_t max_rs = q_row_stride > k_row_stride ? q_row_stride : k_row_stride;
-    if ((max_rs > v_row_stride ? max_rs : v_row_stride) > (1LL << 24)) return CMHSA_ERR_TOO_LARGE;
+    const int64_t max_rs = q_rs > k_rs ? q_rs : k_rs;
+    if ((max_rs > v_rs ? max_rs : v_rs) > (1LL << 24)) return CMHSA_ERR_TOO_LARGE;
+    return CMHSA_OK;
+}
+
+// workspace: null = none (plans that split no block).  acquire: see the kernel template parameter.
+int forward(const float *q, const float *k, const float *v, float *o,
+            int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+            int64_t q_batch_stride, int64_t k_batch_stride, int64_t v_batch_stride, int64_t o_batch_stride,
+            int batch, int seq_len, int num_heads, int head_dim, void *workspace, size_t workspace_bytes,
+            bool reject_short_workspace, bool acquire, void *stream) {
+    int64_t nqb = 0, bh = 0;
+    bool empty = false;
+    const int rc = check_forward_args(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride,
+                                      q_batch_stride, k_batch_stride, v_batch_stride, o_batch_stride,
+                                      batch, seq_len, num_heads, head_dim, nqb, bh, empty);
+    if (rc != CMHSA_OK || empty) return rc;
+    if (workspace && ((uintptr_t)workspace & 255)) return CMHSA_ERR_ALIGNMENT;
 
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-    const Plan plan = cached_plan(bh, (int)nqb, device_cu_count(dev));
+    const int cus = device_cu_count(dev);
+    Plan plan = cached_plan(bh, (int)nqb, cus, workspace != nullptr);
+    if (plan_workspace_bytes(plan, bh) > workspace_bytes) {
+        if (reject_short_workspace) return CMHSA_ERR_WORKSPACE;
+        plan = cached_plan(bh, (int)nqb, cus, false);             // a short workspace selects the plan that needs none
+    }
     const PackPlan &pl = plan.pp;
     const int waves = pl.waves;
     // grid = (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8
@@ -843,13 +1215,76 @@ int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
     p.chain_magic = 0xffffffffu / (unsigned)pl.chain;
     p.chain = pl.chain; p.n_paired = pl.n_paired; p.n_alone = pl.n_alone;
     p.use_table = plan.use_table ? 1 : 0;
-    if (plan.use_table)
-        for (int j = 0; j < plan.n_wgs; ++j)
-            p.seg_table[j] = plan.segs[j][0] | (plan.segs[j][1] << 8) | (plan.segs[j][2] << 16) | ((unsigned)plan.segs[j][3] << 24);
+    const bool split = plan.parts_per_bh > 0;
+    p.ws_counters = split ? static_cast<unsigned *>(workspace) : nullptr;
+    p.ws_parts = split ? reinterpret_cast<float *>(static_cast<char *>(workspace) + kWsCounterBytes) : nullptr;
+    p.parts_per_bh = plan.parts_per_bh;
+    p.splits_per_bh = plan.splits_per_bh;
+    if (plan.use_table) memcpy(p.seg_table, plan.table, sizeof(unsigned) * (size_t)plan.n_wgs * kTableWords);
 
-    hipError_t e = p.use_table ? (waves == 8 ? launch<8, 4>(p, grid, stream) : launch<4, 4>(p, grid, stream))
-                               : (waves == 8 ? launch<8, 2>(p, grid, stream) : launch<4, 2>(p, grid, stream));
+    hipError_t e;
+    if (!p.use_table) e = waves == 8 ? launch<8, 2, false>(p, grid, stream) : launch<4, 2, false>(p, grid, stream);
+    else if (waves == 4) e = launch<4, 4, false>(p, grid, stream);
+    else e = split && acquire ? launch<8, 4, true>(p, grid, stream) : launch<8, 4, false>(p, grid, stream);
     return e == hipSuccess ? CMHSA_OK : (int)e;     // launch-configuration errors only; no synchronisation (CMHSA.cu:450)
+}
+
+}  // namespace
+
+extern "C" {
+
+int cmhsa_fp32_fwd(const float *q, const float *k, const float *v, float *o,
+                   int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                   int64_t q_batch_stride, int64_t k_batch_stride, int64_t v_batch_stride, int64_t o_batch_stride,
+                   int batch, int seq_len, int num_heads, int head_dim, void *stream) {
+    return forward(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_batch_stride, k_batch_stride,
+                   v_batch_stride, o_batch_stride, batch, seq_len, num_heads, head_dim, nullptr, 0, false, false, stream);
+}
+
+int cmhsa_fp32_fwd_ws(const float *q, const float *k, const float *v, float *o,
+                      int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                      int64_t q_batch_stride, int64_t k_batch_stride, int64_t v_batch_stride, int64_t o_batch_stride,
+                      int batch, int seq_len, int num_heads, int head_dim,
+                      void *workspace, size_t workspace_bytes, void *stream) {
+    return forward(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_batch_stride, k_batch_stride,
+                   v_batch_stride, o_batch_stride, batch, seq_len, num_heads, head_dim,
+                   workspace_bytes ? workspace : nullptr, workspace ? workspace_bytes : 0, false, false, stream);
+}
+
+size_t cmhsa_workspace_bytes(void) { return kWsMaxBytes; }
+
+int cmhsa_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
+    if (!workspace) return CMHSA_ERR_NULL_POINTER;
+    if ((uintptr_t)workspace & 255) return CMHSA_ERR_ALIGNMENT;
+    if (workspace_bytes < kWsCounterBytes) return CMHSA_ERR_WORKSPACE;
+    const hipError_t e = hipMemsetAsync(workspace, 0, kWsCounterBytes, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? CMHSA_OK : (int)e;
+}
+
+size_t cmhsa_fp32_fwd_workspace_bytes(int batch, int seq_len, int num_heads) {
+    if (batch <= 0 || seq_len <= 0 || num_heads <= 0) return 0;
+    const int64_t nqb = ((int64_t)seq_len + kQBlock - 1) / kQBlock, bh = (int64_t)batch * num_heads;
+    if ((nqb + 16) * kKeyUnit > 0x7fffffffLL || bh > 0x7fffffffLL) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    return plan_workspace_bytes(cached_plan(bh, (int)nqb, device_cu_count(dev), true), bh);
+}
+
+int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspace, char *buf, int buf_len) {
+    if (!buf || buf_len <= 0) return CMHSA_ERR_NULL_POINTER;
+    buf[0] = 0;
+    if (batch <= 0 || seq_len <= 0 || num_heads <= 0) return CMHSA_ERR_BAD_SHAPE;
+    const int64_t nqb = ((int64_t)seq_len + kQBlock - 1) / kQBlock, bh = (int64_t)batch * num_heads;
+    if ((nqb + 16) * kKeyUnit > 0x7fffffffLL || bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    const int cus = device_cu_count(dev);
+    const Plan pl = cached_plan(bh, (int)nqb, cus, with_workspace != 0);
+    snprintf(buf, (size_t)buf_len, "%s: %d-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, chain cap %d, SIMD cap %d, "
+             "%d of %lld query blocks per (b,h) split across workgroups, workspace %zu B, estimate %.0f cycles",
+             pl.family, pl.pp.waves, pl.pp.wgs_per_bh, (long long)bh, cus, pl.pp.chain, pl.simd_cap, pl.splits_per_bh,
+             (long long)nqb, plan_workspace_bytes(pl, bh), pl.cycles);
+    return CMHSA_OK;
 }
 
 int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,
@@ -862,15 +1297,16 @@ int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,
 
 int cmhsa_fp32_fwd_packed_qkv(const float *qkv, float *o, int64_t qkv_row_stride, int64_t o_row_stride,
                               int64_t qkv_batch_stride, int64_t o_batch_stride,
-                              int batch, int seq_len, int num_heads, int head_dim, void *stream) {
+                              int batch, int seq_len, int num_heads, int head_dim,
+                              void *workspace, size_t workspace_bytes, void *stream) {
     if (num_heads <= 0) return CMHSA_ERR_BAD_SHAPE;
     if (head_dim != kHeadDim) return CMHSA_ERR_HEAD_DIM;
     const int64_t d_model = (int64_t)num_heads * kHeadDim;
     if (qkv_row_stride < 3 * d_model) return CMHSA_ERR_BAD_SHAPE;             // a row must hold Q | K | V
     const float *k = qkv ? qkv + d_model : nullptr, *v = qkv ? qkv + 2 * d_model : nullptr;
-    return cmhsa_fp32_fwd(qkv, k, v, o, qkv_row_stride, qkv_row_stride, qkv_row_stride, o_row_stride,
-                          qkv_batch_stride, qkv_batch_stride, qkv_batch_stride, o_batch_stride,
-                          batch, seq_len, num_heads, head_dim, stream);
+    return cmhsa_fp32_fwd_ws(qkv, k, v, o, qkv_row_stride, qkv_row_stride, qkv_row_stride, o_row_stride,
+                             qkv_batch_stride, qkv_batch_stride, qkv_batch_stride, o_batch_stride,
+                             batch, seq_len, num_heads, head_dim, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -22,6 +22,11 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "cmhsa.h"
@@ -36,6 +41,27 @@ static void check_one(const at::Tensor &t, const char *name, int64_t dim) {
     TORCH_CHECK(t.stride(dim - 1) == 1, name, "'s last-dim stride must be 1 for float4 loads to work");      // :480-482
     TORCH_CHECK(t.stride(dim - 2) % 4 == 0, name, "'s row stride must be a multiple of 4 for float4 loads to work");  // :484-486
     if (dim == 3) TORCH_CHECK(t.stride(0) % 4 == 0, name, "'s batch stride must be a multiple of 4 for float4 loads to work");
+}
+
+// Workspace of cmhsa_fp32_fwd_ws (query blocks split across workgroups), one per (device, stream): calls on one stream
+// are ordered, calls on different streams must not share it.  Allocated and zeroed at a stream's first call; a first
+// call that arrives while the stream is being captured into a graph gets none (no allocation, no memset node in a
+// capture) and runs the plan that needs no workspace.  The tensors live until the process ends.
+static void *stream_workspace(int device, hipStream_t stream, size_t *bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, at::Tensor> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({device, stream});
+    if (it == cache.end()) {
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &status) != hipSuccess || status != hipStreamCaptureStatusNone) { *bytes = 0; return nullptr; }
+        at::Tensor ws = at::empty({(int64_t)cmhsa_workspace_bytes()}, at::TensorOptions().dtype(at::kByte).device(at::kCUDA, device));
+        const int rc = cmhsa_workspace_init(ws.data_ptr(), (size_t)ws.numel(), stream);
+        TORCH_CHECK(rc == CMHSA_OK, "cmhsa_workspace_init failed (", rc, "): ", cmhsa_status_string(rc));
+        it = cache.emplace(std::make_pair(device, stream), ws).first;
+    }
+    *bytes = (size_t)it->second.numel();
+    return it->second.data_ptr();
 }
 
 at::Tensor causal_multihead_self_attention_torch(at::Tensor Q, at::Tensor K, at::Tensor V, int64_t num_heads) {
@@ -65,11 +91,13 @@ at::Tensor causal_multihead_self_attention_torch(at::Tensor Q, at::Tensor K, at:
     const c10::hip::HIPGuard guard(Q.device().index());
     const hipStream_t stream = c10::hip::getCurrentHIPStream(Q.device().index()).stream();
     auto bs = [&](const at::Tensor &t) -> int64_t { return dim == 3 ? t.stride(0) : 0; };
-    const int rc = cmhsa_fp32_fwd(Q.data_ptr<float>(), K.data_ptr<float>(), V.data_ptr<float>(), output.data_ptr<float>(),
-                                  Q.stride(dim - 2), K.stride(dim - 2), V.stride(dim - 2), output.stride(dim - 2),
-                                  bs(Q), bs(K), bs(V), bs(output),
-                                  (int)B, (int)N, (int)num_heads, (int)(d / num_heads), stream);
-    TORCH_CHECK(rc == CMHSA_OK, "cmhsa_fp32_fwd failed (", rc, "): ", cmhsa_status_string(rc));
+    size_t ws_bytes = 0;
+    void *ws = cmhsa_fp32_fwd_workspace_bytes((int)B, (int)N, (int)num_heads) ? stream_workspace(Q.device().index(), stream, &ws_bytes) : nullptr;
+    const int rc = cmhsa_fp32_fwd_ws(Q.data_ptr<float>(), K.data_ptr<float>(), V.data_ptr<float>(), output.data_ptr<float>(),
+                                     Q.stride(dim - 2), K.stride(dim - 2), V.stride(dim - 2), output.stride(dim - 2),
+                                     bs(Q), bs(K), bs(V), bs(output),
+                                     (int)B, (int)N, (int)num_heads, (int)(d / num_heads), ws, ws_bytes, stream);
+    TORCH_CHECK(rc == CMHSA_OK, "cmhsa_fp32_fwd_ws failed (", rc, "): ", cmhsa_status_string(rc));
     return output;
 }
 
@@ -91,9 +119,11 @@ at::Tensor causal_multihead_self_attention_packed_qkv(at::Tensor QKV, int64_t nu
     if (output.numel() == 0) return output;
     const c10::hip::HIPGuard guard(QKV.device().index());
     const hipStream_t stream = c10::hip::getCurrentHIPStream(QKV.device().index()).stream();
+    size_t ws_bytes = 0;
+    void *ws = cmhsa_fp32_fwd_workspace_bytes((int)B, (int)N, (int)num_heads) ? stream_workspace(QKV.device().index(), stream, &ws_bytes) : nullptr;
     const int rc = cmhsa_fp32_fwd_packed_qkv(QKV.data_ptr<float>(), output.data_ptr<float>(), QKV.stride(dim - 2), output.stride(dim - 2),
                                              dim == 3 ? QKV.stride(0) : 0, dim == 3 ? output.stride(0) : 0,
-                                             (int)B, (int)N, (int)num_heads, 64, stream);
+                                             (int)B, (int)N, (int)num_heads, 64, ws, ws_bytes, stream);
     TORCH_CHECK(rc == CMHSA_OK, "cmhsa_fp32_fwd_packed_qkv failed (", rc, "): ", cmhsa_status_string(rc));
     return output;
 }

@@ -125,10 +125,18 @@ class GPT2Model(nn.Module):
 
 
 def build_model(name: str, backend: ScaledDotProductAttentionBackend, device, weights: str | None = None, seed: int = 0,
-                last_position_only: bool = False, overrides: dict | None = None, fused_gelu: bool = False) -> GPT2Model:
+                last_position_only: bool = False, overrides: dict | None = None, fused_gelu: bool = False,
+                init_on_device: bool = False) -> GPT2Model:
+    """init_on_device: draw the random weights on `device` directly (seconds instead of tens of seconds for GPT2-XL;
+    the values then come from the device's generator, not the CPU's -- fine for timing, and every rank that seeds alike
+    gets the same weights).  The default draws them on the CPU, so that CPU and GPU models of one seed are equal."""
     cfg = {**COMMON, **GPT2_CONFIGS[name], **(overrides or {})}
     torch.manual_seed(seed)                       # seeded random weights unless a local checkpoint is given
-    model = GPT2Model(cfg, backend, last_position_only, fused_gelu)
+    if init_on_device and torch.device(device).type != "cpu":
+        with torch.device(device):
+            model = GPT2Model(cfg, backend, last_position_only, fused_gelu)
+    else:
+        model = GPT2Model(cfg, backend, last_position_only, fused_gelu)
     if weights:
         model.load_hf_safetensors(weights)
     return model.eval().to(device)

@@ -99,7 +99,7 @@ def test_missing_library_fails_loudly(monkeypatch):
 def test_packed_qkv_argument_validation_needs_no_gpu():
     lib = cmhsa.load_library()
     null, good = ctypes.c_void_p(0), ctypes.c_void_p(0x1000)
-    call = lambda qkv=good, o=good, rs=3 * 64, ors=64, T=8, H=1, hd=64: lib.cmhsa_fp32_fwd_packed_qkv(qkv, o, rs, ors, 0, 0, 1, T, H, hd, null)
+    call = lambda qkv=good, o=good, rs=3 * 64, ors=64, T=8, H=1, hd=64: lib.cmhsa_fp32_fwd_packed_qkv(qkv, o, rs, ors, 0, 0, 1, T, H, hd, null, 0, null)
     assert call(hd=32) == cmhsa.CMHSA_ERR_HEAD_DIM
     assert call(H=0) == cmhsa.CMHSA_ERR_BAD_SHAPE
     assert call(rs=2 * 64) == cmhsa.CMHSA_ERR_BAD_SHAPE          # a row must hold Q | K | V
