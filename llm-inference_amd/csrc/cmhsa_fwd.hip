@@ -221,6 +221,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     // Pull every kernel argument into SGPRs NOW, with one wait: left alone, hipcc sinks the scalar loads into
     // the blocks that use them -- five dependent round trips to a cold kernarg segment (~2 k cycles, measured)
     // before the first global load could be issued.
+    // (the table variant's eight words of this workgroup ride in the same batch: their address needs blockIdx.y only)
+    unsigned tw[kTableWords];
+    if constexpr (kSegs > 2) {
+#pragma unroll
+        for (int i = 0; i < kTableWords; ++i) tw[i] = p.seg_table[blockIdx.y * kTableWords + i];
+        asm volatile("" ::"s"(tw[0]), "s"(tw[1]), "s"(tw[2]), "s"(tw[3]), "s"(tw[4]), "s"(tw[5]), "s"(tw[6]), "s"(tw[7]),
+                     "s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs), "s"(p.v_rs), "s"(p.o_rs));
+    } else
     asm volatile("" ::"s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs), "s"(p.v_rs), "s"(p.o_rs));
     asm volatile("" ::"s"(p.q_bs), "s"(p.k_bs), "s"(p.v_bs), "s"(p.o_bs), "s"(p.seq_len), "s"(p.num_heads), "s"(p.nqb),
                  "s"(p.grid_x), "s"(p.heads_magic), "s"(p.chain_magic), "s"(p.chain), "s"(p.n_paired), "s"(p.n_alone), "s"(p.use_table));
@@ -236,15 +244,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     int seg_ulo[kSegs], seg_cnt[kSegs];          // the segment covers units [ulo, ulo + cnt) of it (the whole block: 0, n)
     unsigned seg_mask[kSegs], seg_x[kSegs];      // waves working on it (bit w = wave w); table word 1 (0 = not a part)
     if (kSegs > 2) {                              // explicit plan (only this variant is launched with a table)
-        const unsigned *e = p.seg_table + j * kTableWords;
 #pragma unroll
         for (int i = 0; i < kSegs; ++i) {
-            const unsigned w0 = e[2 * i];
+            const unsigned w0 = tw[2 * i];
             seg_n[i] = w0 & 255;
             seg_ulo[i] = (w0 >> 8) & 255;
             seg_cnt[i] = (w0 >> 16) & 255;
             seg_mask[i] = w0 >> 24;
-            seg_x[i] = e[2 * i + 1];
+            seg_x[i] = tw[2 * i + 1];
         }
     } else {                                      // analytic plan: the longest blocks alone, the others paired n <-> R+1-n
 #pragma unroll
@@ -932,7 +939,7 @@ bool pack_attempt(int nqb, int L, bool allow_split, double psplit, Rng &rng, int
     return true;
 }
 
-bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus) {
+bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus, bool eager_split = false) {
     if (nqb > 255 || bh > cus) return false;
     const int g_max = (int)min((int64_t)kMaxTableWgs, (int64_t)cus / bh);
     Rng rng{0x9E3779B97F4A7C15ull ^ ((uint64_t)nqb << 32) ^ ((uint64_t)L << 16) ^ (uint64_t)g_max ^ (allow_split ? 0x5555ull : 0ull)};
@@ -942,7 +949,8 @@ bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus
     // whole blocks first (and parts only where a block cannot fit); then a little optional splitting
     const int tries = allow_split ? 24 : 6;
     for (int t = 0; t < tries && !ok; ++t) {
-        const double psplit = !allow_split || t < 6 ? 0.0 : 0.04 * (1 + (t - 6) / 6);
+        // (eager_split: experiments / tests only -- split blocks although they would fit whole)
+        const double psplit = !allow_split ? 0.0 : eager_split ? 0.2 : t < 6 ? 0.0 : 0.04 * (1 + (t - 6) / 6);
         ok = pack_attempt(nqb, L, allow_split, psplit, rng, g_max, wgs, n_splits);
     }
     if (!ok) return false;
@@ -1036,7 +1044,7 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
             for (int split = 0; split <= (allow_split ? 1 : 0); ++split) {
                 if (forced_split >= 0 && forced_split != split && (allow_split || forced_split == 0)) continue;
                 Plan pl;
-                if (!packed_plan(pl, nqb, L, split != 0, bh, cus)) continue;
+                if (!packed_plan(pl, nqb, L, split != 0, bh, cus, split != 0 && forced_split == 1)) continue;
                 if (split && !pl.splits_per_bh) continue;            // the same plan as split = 0
                 if (!have || pl.cycles < best.cycles * 0.98) { best = pl; have = true; }
             }

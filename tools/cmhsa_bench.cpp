@@ -1,6 +1,7 @@
 // cmhsa_bench.cpp -- native (no Python, no torch) driver of the C ABI in include/cmhsa.h.
 // Used for rocprofv3 counter passes (the program after `--` must not re-exec) and for quick
-// A/B timing of kernel variants.  Build:  make -C tools     Run:  tools/cmhsa_bench B H T [steps] [warmup]
+// A/B timing of kernel variants.  Build:  make -C tools     Run:  tools/cmhsa_bench B H T [steps] [warmup] [stamped block] [nows]
+// (the seventh argument "nows" calls cmhsa_fp32_fwd, the entry point without a workspace; default: cmhsa_fp32_fwd_ws)
 // Inputs are U[0,1) (the reference test's distribution, test_torch_extension.py:16-18) laid out as
 // QKV column slices of one (B, T, 3*d_model) buffer, exactly what the model hands over.
 #include <hip/hip_runtime.h>
@@ -8,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 #include <algorithm>
 
@@ -34,9 +36,21 @@ int main(int argc, char **argv) {
     CHECK(hipMemcpy(qkv, h.data(), n_in * sizeof(float), hipMemcpyHostToDevice));
     hipStream_t s;
     CHECK(hipStreamCreate(&s));
+    const bool use_ws = !(argc > 7 && std::string(argv[7]) == "nows");
+    void *ws = nullptr;
+    const size_t ws_bytes = use_ws ? cmhsa_workspace_bytes() : 0;
+    if (use_ws) {
+        CHECK(hipMalloc(&ws, ws_bytes));
+        if (int rc = cmhsa_workspace_init(ws, ws_bytes, s)) { fprintf(stderr, "cmhsa: %s\n", cmhsa_status_string(rc)); return 1; }
+    }
+    {
+        char desc[512];
+        cmhsa_plan_describe(B, T, H, use_ws ? 1 : 0, desc, sizeof(desc));
+        fprintf(stderr, "plan: %s\n", desc);
+    }
     auto run = [&]() {
-        return cmhsa_fp32_fwd(qkv, qkv + d, qkv + 2 * d, o, rs, rs, rs, d, (int64_t)T * rs, (int64_t)T * rs, (int64_t)T * rs,
-                              (int64_t)T * d, B, T, H, 64, s);
+        return cmhsa_fp32_fwd_ws(qkv, qkv + d, qkv + 2 * d, o, rs, rs, rs, d, (int64_t)T * rs, (int64_t)T * rs, (int64_t)T * rs,
+                                 (int64_t)T * d, B, T, H, 64, ws, ws_bytes, s);
     };
     for (int i = 0; i < warmup; ++i) if (int rc = run()) { fprintf(stderr, "cmhsa: %s\n", cmhsa_status_string(rc)); return 1; }
     hipEvent_t e0, e1;
