@@ -109,7 +109,7 @@ def test_torch_op_equals_c_abi_bitwise(gpu_device):
     qkv = torch.randn(300, 3 * 768, device=gpu_device)
     Q, K, V = qkv[:, :768], qkv[:, 768:1536], qkv[:, 1536:]
     a = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_torch(Q=Q, K=K, V=V, num_heads=12)
-    b = cmhsa.attention_fwd(Q, K, V, 12)
+    b = cmhsa.attention_fwd(Q, K, V, 12, workspace=cmhsa.Workspace(gpu_device))     # the op runs with its stream's workspace
     assert torch.equal(a, b)
     assert a.shape == (300, 768) and a.is_contiguous()
 
@@ -318,10 +318,15 @@ def test_packed_qkv_entry_point_equals_the_three_view_call(gpu_device):
         qkv = torch.randn(B, T, 3 * d, device=gpu_device)
         want = cmhsa.attention_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H)
         assert torch.equal(cmhsa.attention_fwd_packed_qkv(qkv, H), want)
+        ws = cmhsa.Workspace(gpu_device)                  # with a workspace both forms may split query blocks: same plan, same bits
+        want_ws = cmhsa.attention_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], H, workspace=ws)
+        assert torch.equal(cmhsa.attention_fwd_packed_qkv(qkv, H, workspace=ws), want_ws)
+        assert (want_ws - want).abs().max().item() <= 5e-6
+        # the torch ops run with their stream's workspace
         op = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_packed_qkv
-        assert torch.equal(op(QKV=qkv, num_heads=H), want)
+        assert torch.equal(op(QKV=qkv, num_heads=H), want_ws)
         if B == 1:
-            assert torch.equal(op(QKV=qkv[0], num_heads=H), want[0])
+            assert torch.equal(op(QKV=qkv[0], num_heads=H), want_ws[0])
     # padded rows (row stride > 3*d_model) are fine, too-narrow / mis-shaped inputs raise
     wide = torch.randn(50, 3 * 768 + 64, device=gpu_device)
     got = cmhsa.attention_fwd_packed_qkv(wide[:, :3 * 768], 12)
