@@ -88,6 +88,24 @@ int cmhsa_fp32_fwd_ws(const float *q, const float *k, const float *v, float *o,
                       int batch, int seq_len, int num_heads, int head_dim,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same forward for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its launcher needs no scratch memory, CMHSA.cu:409-462).
+ * It is cmhsa_fp32_fwd_ws with the workspace taken from a static array in device memory that the library's code
+ * object carries: CMHSA_NOALLOC_SCRATCH_BYTES (1 MiB) on every GPU the library runs on, held until the process ends.
+ * The call allocates nothing (no hipMalloc / hipFree, no allocating library routine); the array's address on the
+ * current device is looked up once per device (hipGetSymbolAddress, at the first call on that device).
+ *   - A shape whose plan needs more scratch than the array holds is rejected with CMHSA_ERR_WORKSPACE (nothing is
+ *     launched); cmhsa_fp32_fwd_workspace_bytes() tells the need in advance.  BASELINE config 2 needs 0.8 MiB.
+ *   - Every call on a GPU shares that GPU's array: calls that OVERLAP in time on one GPU (different streams) race.
+ *     The kernel itself leaves the array's arrival counters zero, so back-to-back calls need no re-initialisation.
+ *   - Results equal cmhsa_fp32_fwd_ws's bit for bit (same plan, same arithmetic); the merging workgroup additionally
+ *     runs an agent-scope acquire, which costs about a microsecond on shapes that split query blocks. */
+#define CMHSA_NOALLOC_SCRATCH_BYTES ((size_t)1048576)
+int cmhsa_fp32_fwd_noalloc(const float *q, const float *k, const float *v, float *o,
+                           int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                           int64_t q_batch_stride, int64_t k_batch_stride, int64_t v_batch_stride, int64_t o_batch_stride,
+                           int batch, int seq_len, int num_heads, int head_dim, void *stream);
+
 /* CMHSA_WORKSPACE_BYTES as a function (for bindings that cannot read the macro). */
 size_t cmhsa_workspace_bytes(void);
 

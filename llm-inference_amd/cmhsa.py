@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "cmhsa_version",
     "cmhsa_fp32_fwd",
     "cmhsa_fp32_fwd_ws",
+    "cmhsa_fp32_fwd_noalloc",
     "cmhsa_workspace_bytes",
     "cmhsa_workspace_init",
     "cmhsa_fp32_fwd_workspace_bytes",
@@ -52,6 +53,7 @@ CMHSA_ERR_HEAD_DIM = -3
 CMHSA_ERR_ALIGNMENT = -4
 CMHSA_ERR_TOO_LARGE = -5
 CMHSA_ERR_WORKSPACE = -6
+NOALLOC_SCRATCH_BYTES = 1 << 20          # CMHSA_NOALLOC_SCRATCH_BYTES (include/cmhsa.h)
 
 _lib = None
 
@@ -81,6 +83,8 @@ def load_library() -> ctypes.CDLL:
     lib.cmhsa_fp32_fwd.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp]
     lib.cmhsa_fp32_fwd_ws.restype = i32
     lib.cmhsa_fp32_fwd_ws.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp, sz, vp]
+    lib.cmhsa_fp32_fwd_noalloc.restype = i32
+    lib.cmhsa_fp32_fwd_noalloc.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp]
     lib.cmhsa_workspace_bytes.restype = sz
     lib.cmhsa_workspace_bytes.argtypes = []
     lib.cmhsa_workspace_init.restype = i32

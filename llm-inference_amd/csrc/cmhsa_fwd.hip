@@ -1077,6 +1077,33 @@ Plan cached_plan(int64_t bh, int nqb, int cus, bool allow_split) {
     return cache.back().plan;                        // by value: the entry may be gone once the lock is released
 }
 
+// ---- the no-allocation entry point's scratch: a file-scope array in device memory.  In HOST code the name `scratch`
+// is only a stand-in (not a device address): its address on each device comes from hipGetSymbolAddress, once per
+// device, and only that pointer is ever handed to a kernel.  Zero-initialised at module load, like every arrival
+// counter the kernel leaves behind.
+static __device__ __align__(256) unsigned char scratch[CMHSA_NOALLOC_SCRATCH_BYTES];
+static_assert(CMHSA_NOALLOC_SCRATCH_BYTES > kWsCounterBytes + kPartFloats * 4 && CMHSA_NOALLOC_SCRATCH_BYTES % 256 == 0, "scratch size");
+
+std::mutex g_scratch_mu;
+void *g_scratch_ptr[64];                         // per device: each GPU holds its own copy of the array at its own address
+
+int scratch_of_current_device(void **ptr) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return CMHSA_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));            // with device `dev` current: ITS copy of the array
+        if (e != hipSuccess) return (int)e;
+        if (!p || ((uintptr_t)p & 255)) return CMHSA_ERR_ALIGNMENT;
+        g_scratch_ptr[dev] = p;
+    }
+    *ptr = g_scratch_ptr[dev];
+    return CMHSA_OK;
+}
+
 size_t plan_workspace_bytes(const Plan &pl, int64_t bh) {
     return pl.parts_per_bh ? kWsCounterBytes + (size_t)bh * pl.parts_per_bh * kPartFloats * 4 : 0;
 }
@@ -1127,7 +1154,8 @@ const char *cmhsa_status_string(int status) {
         case CMHSA_ERR_HEAD_DIM: return "Head dimension must be 64.";
         case CMHSA_ERR_ALIGNMENT: return "pointers must be 16-byte aligned and row/batch strides multiples of 4 for float4 loads to work";
         case CMHSA_ERR_TOO_LARGE: return "problem too large for 32-bit tile indexing";
-        case CMHSA_ERR_WORKSPACE: return "workspace too small for this shape's plan";
+        case CMHSA_ERR_WORKSPACE: return "workspace too small (cmhsa_fp32_fwd_noalloc: this shape's plan needs more than the static "
+                                         "CMHSA_NOALLOC_SCRATCH_BYTES; use cmhsa_fp32_fwd_ws with a workspace, or cmhsa_fp32_fwd)";
         default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown cmhsa status";
     }
 }
@@ -1257,6 +1285,20 @@ int cmhsa_fp32_fwd_ws(const float *q, const float *k, const float *v, float *o,
     return forward(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_batch_stride, k_batch_stride,
                    v_batch_stride, o_batch_stride, batch, seq_len, num_heads, head_dim,
                    workspace_bytes ? workspace : nullptr, workspace ? workspace_bytes : 0, false, false, stream);
+}
+
+int cmhsa_fp32_fwd_noalloc(const float *q, const float *k, const float *v, float *o,
+                           int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                           int64_t q_batch_stride, int64_t k_batch_stride, int64_t v_batch_stride, int64_t o_batch_stride,
+                           int batch, int seq_len, int num_heads, int head_dim, void *stream) {
+    void *ptr = nullptr;
+    const int rc = scratch_of_current_device(&ptr);
+    if (rc != CMHSA_OK) return rc;
+    // a plan that needs more than the static array is REJECTED (CMHSA_ERR_WORKSPACE), not replaced; the workgroup that
+    // merges a split block runs an agent-scope acquire first (the array is not hipMalloc memory)
+    return forward(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride, q_batch_stride, k_batch_stride,
+                   v_batch_stride, o_batch_stride, batch, seq_len, num_heads, head_dim, ptr, CMHSA_NOALLOC_SCRATCH_BYTES,
+                   true, true, stream);
 }
 
 size_t cmhsa_workspace_bytes(void) { return kWsMaxBytes; }
