@@ -258,11 +258,16 @@ class Bench:
         out = torch.empty((B, T, d), device=self.dev)
         call_args = self.fwd_args(Q, K, V, out, B, T, H)
         gathered = torch.empty((world * B, T, d), device=self.dev) if sharded and world > 1 else None
+        if gathered is not None and self.backend != "nccl":
+            import sharded_attention as sa                   # rehearsal: gloo gathers through host memory
 
         def step() -> None:
             self.launch(call_args)
             if gathered is not None:                         # the one collective of the head-sharded form
-                self.dist.all_gather_into_tensor(gathered, out)
+                if self.backend == "nccl":
+                    self.dist.all_gather_into_tensor(gathered, out)
+                else:
+                    sa.all_gather_dim0(out, world)
 
         ramp = self.device_ramp(step, args.ramp_ms)
         for _ in range(args.warmup):
@@ -523,7 +528,7 @@ class Bench:
         slab = sa.head_sharded_attention(Q, K, V, H_total, compute, gather=False).contiguous()
         flat = torch.empty((world * B, T, 64 * per), device=self.dev)
         comp_ms = span(lambda: sa.head_sharded_attention(Q, K, V, H_total, compute, gather=False))
-        ag_ms = span(lambda: dist.all_gather_into_tensor(flat, slab))
+        ag_ms = span((lambda: dist.all_gather_into_tensor(flat, slab)) if self.backend == "nccl" else (lambda: sa.all_gather_dim0(slab, world)))
         e2e_ms = span(lambda: sa.head_sharded_attention(Q, K, V, H_total, compute))
         comp_ms, ag_ms, e2e_ms = self.max_over_ranks(comp_ms, ag_ms, e2e_ms)
         full = sa.head_sharded_attention(Q, K, V, H_total, compute)

@@ -19,6 +19,21 @@ import torch
 import torch.distributed as dist
 
 
+def all_gather_dim0(t: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """ONE all-gather of equal contiguous tensors into (world * t.shape[0], ...).  RCCL ("nccl") moves device memory
+    over xGMI directly.  gloo is a host backend (CPU tests, and rehearsals of the N > 1 code path on a one-GPU box):
+    device tensors are staged through host memory here, explicitly -- gloo's own handling of device tensors stalls
+    after a few dozen collectives on this stack."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        flat = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(flat, host, group=group)
+        return flat.to(t.device)
+    flat = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(flat, t, group=group)
+    return flat
+
+
 def head_slab(t: torch.Tensor, num_heads: int, rank: int, world: int, head_dim: int = 64) -> torch.Tensor:
     """This rank's heads of a (..., H*head_dim) tensor, as a strided VIEW (the kernel takes row strides)."""
     if num_heads % world != 0:
@@ -45,8 +60,7 @@ def head_sharded_attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, nu
         return slab
     slab = slab.contiguous()
     # output = the W slabs concatenated along dim 0 (the layout every backend's all-gather-into-tensor accepts)
-    flat = torch.empty((world * slab.shape[0],) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
-    dist.all_gather_into_tensor(flat, slab, group=group)
+    flat = all_gather_dim0(slab, world, group)
     buf = flat.view((world,) + tuple(slab.shape))
     # (W, B, T, per*hd) -> (B, T, W, per*hd) -> (B, T, H*hd)
     return buf.movedim(0, -2).reshape(*slab.shape[:-1], world * slab.shape[-1])
@@ -69,8 +83,7 @@ def batch_sharded_attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, n
     cap = base + (1 if extra else 0)
     pad = Q.new_zeros((cap,) + tuple(Q.shape[1:]))
     pad[:hi - lo] = out
-    flat = torch.empty((world * cap,) + tuple(pad.shape[1:]), dtype=pad.dtype, device=pad.device)
-    dist.all_gather_into_tensor(flat, pad, group=group)
+    flat = all_gather_dim0(pad, world, group)
     buf = flat.view((world,) + tuple(pad.shape))
     parts = [buf[r, :base + (1 if r < extra else 0)] for r in range(world)]
     return torch.cat(parts, dim=0)

@@ -73,3 +73,86 @@ def test_bench_refuses_mismatched_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env={**os.environ, "WORLD_SIZE": "1"})
     assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+def _gpu_worker(rank, world, port, backend, out_dir):
+    """The REAL multi-GPU path: sharded_attention.head_sharded_attention / batch_sharded_attention with the HIP kernel
+    (cmhsa.attention_fwd through the C ABI, with a workspace) as `compute`.  world 1: RCCL on cuda:0; world 2: both
+    ranks share cuda:0 over gloo (RCCL refuses two ranks on one device; an 8-GPU node is the driver's to run)."""
+    for p in (ROOT, os.path.join(ROOT, "llm-inference_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    try:
+        import cmhsa
+        import sharded_attention as sa
+        from oracle import naive_attention as oracle
+
+        ws = cmhsa.Workspace(dev)
+        compute = lambda q, k, v, h: cmhsa.attention_fwd(q, k, v, h, workspace=ws)
+        g = torch.Generator().manual_seed(321)                      # same inputs on every rank
+        B, T, H = 2, 333, 8
+        d = 64 * H
+        x = torch.randn(B, T, 3 * d, generator=g).to(dev)
+        Q, K, V = x[..., :d], x[..., d:2 * d], x[..., 2 * d:]
+        got = sa.head_sharded_attention(Q, K, V, H, compute)
+        assert got.shape == (B, T, d) and got.is_contiguous()
+        mine = sa.head_sharded_attention(Q, K, V, H, compute, gather=False)
+        per = d // world
+        assert torch.equal(mine, got[..., rank * per:(rank + 1) * per])
+        got_b = sa.batch_sharded_attention(Q, K, V, H, compute, gather=True)
+        want = oracle.naive_attention_f64(Q.cpu().numpy(), K.cpu().numpy(), V.cpu().numpy(), H)
+        err = max(float(np.abs(got.cpu().numpy() - want).max()), float(np.abs(got_b.cpu().numpy() - want).max()))
+        np.save(os.path.join(out_dir, f"gpu_err_{rank}.npy"), np.asarray(err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+def test_sharded_attention_drives_the_hip_kernel(world, backend, tmp_path):
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(world, port, backend, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert float(np.load(tmp_path / f"gpu_err_{r}.npy")) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks_in_rehearsal_mode():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts its own two ranks (the parent never
+    touches the GPU) and relays rank 0's JSON line.  Rehearsal backend gloo: both ranks share the one GPU of the
+    box, so the numbers mean nothing -- the code path (headline, config-5 leg through sharded_attention, config-4
+    data-parallel leg) is what runs."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CMHSA_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--ramp-ms", "5",
+                        "--gen-budget", "60"], capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert "REHEARSAL" in line["data"]
+    c5 = line["config5"]
+    assert c5["gathered_max_abs_err_vs_f64_oracle"] <= 1e-4 and c5["end_to_end_ms_incl_permute"] > 0
+    c4 = line["config4_dp"]
+    assert c4["tokens_generated_all_gpus"] > 0 and c4["rows_identical_on_rank0"]
+
+
+def test_bench_self_launch_relays_child_failure_on_a_box_without_gpu():
+    """No WORLD_SIZE in the environment and --gpus 2: the parent starts two ranks and must itself stay off the GPU.
+    On a CPU-only box the ranks exit with "needs a GPU"; the parent reports it and exits non-zero.  (On the GPU box the
+    same command succeeds: test_bench_self_launches_two_ranks_in_rehearsal_mode.)"""
+    import subprocess
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0
+    assert "child ranks exited" in r.stderr and "needs a GPU" in r.stderr
