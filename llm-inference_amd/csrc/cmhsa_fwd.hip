@@ -189,6 +189,12 @@ __device__ __forceinline__ void store_unit(float *lds, int lane, const f32x4 (&r
     }
 }
 
+// one float4 of the output.  Plain stores: write-through (sc1) stores of O measured +10 us on BASELINE config 2,
+// non-temporal ones +0.45 us (tools/ab_run.sh).
+__device__ __forceinline__ void store_o(float *ptr, f32x4 v, bool in_range) {
+    if (in_range) *reinterpret_cast<f32x4 *>(ptr) = v;
+}
+
 // floor(n / d) for wave-uniform n, d >= 1 with magic = floor((2^32 - 1) / d): the estimate mulhi(n, magic) is
 // the quotient or one below it for every 32-bit n, so one correction step makes it exact.  A handful of
 // scalar instructions instead of the ~30-instruction float-reciprocal sequence hipcc emits for `/`.
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 } else {
                     acc *= 1.0f / l_tot;
                     const int row = (seg_n[sg] - 1) * kQBlock + l31;
-                    if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
+                    store_o(og + (int64_t)row * p.o_rs + col, acc, row < N);
                 }
             }
         }
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                         acc *= 1.0f / l_tot;
                         const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);
                         const int row = (seg_n[sg] - 1) * kQBlock + l31;
-                        if (row < N) *reinterpret_cast<f32x4 *>(og + (int64_t)row * p.o_rs + col) = acc;
+                        store_o(og + (int64_t)row * p.o_rs + col, acc, row < N);
                     }
                 }
             }
