@@ -1056,11 +1056,19 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
             }
         }
     }
-    if (!have) {                                     // several rounds (or an impossible forced combination)
-        best = Plan();
-        best.pp = pack_plan(nqb, 4);
-        best.use_table = false;
-        best.n_wgs = best.pp.wgs_per_bh;
+    // the default for grids of several rounds: the analytic plan with 4-wave workgroups at the smallest c, two workgroups
+    // per CU.  Priced as (rounds + a quarter for the tail) x (kFixed + the 2 c units a SIMD runs for its two workgroups):
+    // B=4, H=12, T=1024 measures 68.8 us so (est. 174 k cycles) against 79.8 us for the best single-round candidate (a
+    // chain table with c = 24), B=16 248 us (est. 635 k cycles).
+    {
+        Plan multi;
+        multi.pp = pack_plan(nqb, 4);
+        multi.use_table = false;
+        multi.n_wgs = multi.pp.wgs_per_bh;
+        const double rounds = (double)bh * multi.n_wgs / (2.0 * cus);
+        multi.cycles = (fmax(rounds, 1.0) + 0.25) * (kFixedCycles + 2.0 * multi.pp.chain * kUnitCycles);
+        multi.family = "analytic, several rounds";
+        if (!have || (rounds > 1.0 && !forced_old && !forced_packed && multi.cycles < best.cycles * 0.98)) { best = multi; have = true; }
     }
     static const bool verbose = env_int("CMHSA_VERBOSE", 0) != 0;
     if (verbose)

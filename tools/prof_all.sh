@@ -34,6 +34,7 @@ for CFG in "config2 1 12 1024 50" "config5_shard 32 2 4096 10"; do
   set -- $CFG
   TAG=$1
   step "rocprofv3 --pmc passes, $TAG"
+  mkdir -p "$OUT/pmc_$TAG"
   i=0
   for P in "$P1" "$P2" "$P3" "$P4"; do
     i=$((i+1))
