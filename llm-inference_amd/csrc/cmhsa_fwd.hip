@@ -821,6 +821,16 @@ void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
     price(pl, blocks, pl.pp.wgs_per_bh, bh, cus);
 }
 
+// Experiments only (tests/helpers/libcmhsa_hip_planenv.so and tools/ build the library with -DCMHSA_PLAN_ENV):
+// CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force an analytic / chain plan, CMHSA_PACKED=L forces a packed plan
+// with SIMD cap L (CMHSA_SPLIT=0|1: without / with blocks split across workgroups), CMHSA_VERBOSE prints the choice.
+// The shipped library reads no environment variable.
+#ifdef CMHSA_PLAN_ENV
+int env_int(const char *name, int fallback) { const char *e = getenv(name); return e ? atoi(e) : fallback; }
+#else
+constexpr int env_int(const char *, int fallback) { return fallback; }
+#endif
+
 // ---- packed plans: 8-wave workgroups, one per CU -------------------------------------------------------------------
 // Work items = whole query blocks, or the two parts of a block cut at a unit boundary.  Items go, longest first (with a
 // little seeded jitter, so that a failed attempt is followed by a different one), into the fullest workgroup that
@@ -868,7 +878,9 @@ unsigned best_slots(const PackWg &wg, int cnt, int g, int cap) {
     return best;
 }
 
-bool pack_attempt(int nqb, int L, bool allow_split, double psplit, Rng &rng, int g_max, std::vector<PackWg> &wgs, int &n_splits) {
+// wave_share: preferred units per wave as a fraction of the SIMD cap: 1/2 = two equal waves per SIMD; up to 1 = one
+// long chain per SIMD (fewer waves per block, for plans with few workgroups per (b,h), where wave slots are scarce)
+bool pack_attempt(int nqb, int L, bool allow_split, double psplit, double wave_share, Rng &rng, int g_max, std::vector<PackWg> &wgs, int &n_splits) {
     const int Lp = L - 1;
     std::vector<PackItem> items;
     n_splits = 0;
@@ -913,7 +925,7 @@ bool pack_attempt(int nqb, int L, bool allow_split, double psplit, Rng &rng, int
             if (same_block) continue;                                   // both parts of a block in one workgroup: pointless
             // wave counts to try: from two waves per SIMD's worth upwards, then -- longer chains, one wave on a SIMD --
             // downwards to the fewest waves the cap allows
-            const int wcap = (cap + 1) / 2, free_slots = 8 - __builtin_popcount(wg.used);
+            const int wcap = max(1, min(cap, (int)ceil(cap * wave_share))), free_slots = 8 - __builtin_popcount(wg.used);
             const int g_pref = (it.cnt + wcap - 1) / wcap, g_abs = (it.cnt + cap - 1) / cap, g_hi = min(free_slots, it.cnt);
             for (int step = 0; step < 16; ++step) {
                 const int g = step < 8 ? g_pref + step : g_pref - 1 - (step - 8);
@@ -934,13 +946,25 @@ bool pack_attempt(int nqb, int L, bool allow_split, double psplit, Rng &rng, int
             }
             if (placed) {
                 if (j < 0) {
-                    if ((int)wgs.size() == g_max) return false;
+                    if ((int)wgs.size() == g_max) {
+#ifdef CMHSA_PLAN_ENV
+                        if (getenv("CMHSA_VERBOSE") && atoi(getenv("CMHSA_VERBOSE")) > 1)
+                            fprintf(stderr, "pack_attempt L=%d: block %d [%d,+%d) would open workgroup %d of %d\n", L, it.n, it.lo, it.cnt, g_max + 1, g_max);
+#endif
+                        return false;
+                    }
                     wgs.push_back(fresh);
                 }
                 break;
             }
         }
-        if (!placed) return false;
+        if (!placed) {
+#ifdef CMHSA_PLAN_ENV
+            if (getenv("CMHSA_VERBOSE") && atoi(getenv("CMHSA_VERBOSE")) > 1)
+                fprintf(stderr, "pack_attempt L=%d: no place for block %d units [%d,+%d) with %zu workgroups open\n", L, it.n, it.lo, it.cnt, wgs.size());
+#endif
+            return false;
+        }
     }
     return true;
 }
@@ -948,19 +972,42 @@ bool pack_attempt(int nqb, int L, bool allow_split, double psplit, Rng &rng, int
 bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus, bool eager_split = false) {
     if (nqb > 255 || bh > cus) return false;
     const int g_max = (int)min((int64_t)kMaxTableWgs, (int64_t)cus / bh);
-    Rng rng{0x9E3779B97F4A7C15ull ^ ((uint64_t)nqb << 32) ^ ((uint64_t)L << 16) ^ (uint64_t)g_max ^ (allow_split ? 0x5555ull : 0ull)};
-    std::vector<PackWg> wgs;
-    int n_splits = 0;
-    bool ok = false;
+    Rng rng{0x9E3779B97F4A7C15ull ^ ((uint64_t)nqb << 32) ^ ((uint64_t)L << 16) ^ (uint64_t)g_max ^ (allow_split ? 0x5555ull : 0ull)
+            ^ ((uint64_t)env_int("CMHSA_SEED", 0) << 40)};
+    // Up to four packings that fit are priced and the cheapest is kept (the first on ties): a workgroup's time =
+    // kFixed + its busiest SIMD's units * kUnit + kHandoff for the first PART it holds, 0.3 kHandoff for each further one
+    // -- three parts in one full workgroup measured +6 % on BASELINE config 2, two parts +1 % (tools/seed_sweep.sh).
+    std::vector<PackWg> wgs, cand;
+    int n_splits = 0, cand_splits = 0, found = 0;
+    double best_max = 0.0, best_sum = 0.0;
+    auto price_wgs = [](const std::vector<PackWg> &v, double &worst, double &sum) {
+        worst = sum = 0.0;
+        for (const PackWg &wg : v) {
+            int busiest = 0, parts = 0;
+            for (int sidx = 0; sidx < 4; ++sidx) busiest = max(busiest, wg.load[sidx] + wg.load[sidx + 4]);
+            for (int t = 0; t < wg.nseg; ++t) parts += wg.seg_split[t] >= 0;
+            const double c = kFixedCycles + busiest * kUnitCycles + (parts ? kHandoffCycles * (0.7 + 0.3 * parts) : 0.0);
+            worst = fmax(worst, c);
+            sum += c;
+        }
+    };
     // whole blocks first (and parts only where a block cannot fit); then a little optional splitting
-    const int tries = allow_split ? 24 : 6;
-    for (int t = 0; t < tries && !ok; ++t) {
+    const int tries = allow_split ? 24 : 9;
+    for (int t = 0; t < tries && found < 4; ++t) {
         // (eager_split: experiments / tests only -- split blocks although they would fit whole)
         const double psplit = !allow_split ? 0.0 : eager_split ? 0.2 : t < 6 ? 0.0 : 0.04 * (1 + (t - 6) / 6);
-        ok = pack_attempt(nqb, L, allow_split, psplit, rng, g_max, wgs, n_splits);
+        // two equal waves per SIMD first (measured best on BASELINE config 2); longer chains only when that cannot be packed
+        const double wave_share = allow_split ? (t < 12 ? 0.5 : t % 2 ? 0.75 : 1.0) : (t < 3 ? 0.5 : t < 6 ? 0.75 : 1.0);
+        if (!pack_attempt(nqb, L, allow_split, psplit, wave_share, rng, g_max, cand, cand_splits)) continue;
+        if (bh * cand_splits * 2 > (int64_t)kWsMaxParts || bh * cand_splits * 4 > (int64_t)kWsCounterBytes) continue;
+        double worst, sum;
+        price_wgs(cand, worst, sum);
+        if (!found || worst < best_max - 1.0 || (worst < best_max + 1.0 && sum < best_sum - 1.0)) {
+            wgs = cand; n_splits = cand_splits; best_max = worst; best_sum = sum;
+        }
+        ++found;
     }
-    if (!ok) return false;
-    if (bh * n_splits * 2 > (int64_t)kWsMaxParts || bh * n_splits * 4 > (int64_t)kWsCounterBytes) return false;
+    if (!found) return false;
     std::stable_sort(wgs.begin(), wgs.end(), [](const PackWg &a, const PackWg &b) { return a.total > b.total; });   // heaviest first
     pl.pp = pack_plan(nqb, 8, (L + 1) / 2);
     pl.pp.wgs_per_bh = (int)wgs.size();
@@ -971,12 +1018,8 @@ bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus
     pl.splits_per_bh = n_splits;
     pl.parts_per_bh = 2 * n_splits;
     pl.single_round = true;
-    double longest = 0.0;
     for (int j = 0; j < pl.n_wgs; ++j) {
         const PackWg &wg = wgs[j];
-        int busiest = 0;
-        for (int sidx = 0; sidx < 4; ++sidx) busiest = max(busiest, wg.load[sidx] + wg.load[sidx + 4]);
-        longest = fmax(longest, kFixedCycles + busiest * kUnitCycles + (wg.partial ? kHandoffCycles : 0.0));
         for (int t = 0; t < kMaxSeg; ++t) {
             unsigned w0 = 0, w1 = 0;
             if (t < wg.nseg) {
@@ -988,19 +1031,9 @@ bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus
             pl.table[j * kTableWords + 2 * t + 1] = w1;
         }
     }
-    pl.cycles = longest;
+    pl.cycles = best_max;
     return true;
 }
-
-// Experiments only (tests/helpers/libcmhsa_hip_planenv.so and tools/ build the library with -DCMHSA_PLAN_ENV):
-// CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force an analytic / chain plan, CMHSA_PACKED=L forces a packed plan
-// with SIMD cap L (CMHSA_SPLIT=0|1: without / with blocks split across workgroups), CMHSA_VERBOSE prints the choice.
-// The shipped library reads no environment variable.
-#ifdef CMHSA_PLAN_ENV
-int env_int(const char *name, int fallback) { const char *e = getenv(name); return e ? atoi(e) : fallback; }
-#else
-constexpr int env_int(const char *, int fallback) { return fallback; }
-#endif
 
 int device_cu_count(int dev) {
     static std::atomic<int> cached[64];
@@ -1074,6 +1107,17 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
     if (verbose)
         fprintf(stderr, "cmhsa plan: bh=%lld nqb=%d cus=%d -> %s, waves=%d chain=%d simd cap=%d wgs/bh=%d split blocks/bh=%d est=%.0f cycles\n",
                 (long long)bh, nqb, cus, best.family, best.pp.waves, best.pp.chain, best.simd_cap, best.n_wgs, best.splits_per_bh, best.cycles);
+#ifdef CMHSA_PLAN_ENV
+    if (env_int("CMHSA_VERBOSE", 0) > 1 && best.use_table)
+        for (int j = 0; j < best.n_wgs; ++j) {
+            fprintf(stderr, "  wg %2d:", j);
+            for (int t = 0; t < kMaxSeg; ++t) {
+                const unsigned w0 = best.table[j * kTableWords + 2 * t], w1 = best.table[j * kTableWords + 2 * t + 1];
+                if (w0 & 255u) fprintf(stderr, "  block %u units [%u,+%u) waves %02x%s", w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 ? " PART" : "");
+            }
+            fprintf(stderr, "\n");
+        }
+#endif
     return best;
 }
 
