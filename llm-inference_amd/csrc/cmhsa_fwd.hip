@@ -71,7 +71,8 @@ static_assert(kWsMaxBytes == CMHSA_WORKSPACE_BYTES, "include/cmhsa.h and the ker
 constexpr int lds_floats_q(int waves) { return waves * kUnitFloats; }
 constexpr int lds_floats_ml(int waves, int segs) { return (waves + segs) * kUnitFloats; }
 constexpr int lds_floats_flags(int waves, int segs) { return lds_floats_ml(waves, segs) + waves * 64; }
-constexpr int lds_bytes(int waves, int segs) { return (lds_floats_flags(waves, segs) + 4) * 4; }   // <= 98 KiB (8 waves), 65 KiB (4)
+// (one-wave workgroups keep nothing but their K unit in LDS: no shared query blocks, no merge)
+constexpr int lds_bytes(int waves, int segs) { return waves == 1 ? kUnitFloats * 4 : (lds_floats_flags(waves, segs) + 4) * 4; }   // <= 98 KiB (8 waves), 65 KiB (4), 8 KiB (1)
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
 constexpr int kSc1 = 16;                                   // buffer load/store aux bits on gfx950: 16 = sc1 (agent-coherent: stores write through, loads bypass the CU's L1)
 constexpr float kRescaleSum = 1.8446744e19f;              // 2^64: a row sum of P above it triggers the rescale path
@@ -135,7 +136,8 @@ inline PackPlan pack_plan(int nqb, int waves, int chain = 0) {
     PackPlan pl;
     pl.waves = waves;
     pl.chain = chain > 0 ? chain : (nqb + waves - 1) / waves;
-    pl.n_paired = (int)min((int64_t)nqb, (int64_t)pl.chain * (waves - 1));
+    // (one-wave workgroups: every block is paired, n <-> nqb+1-n, and a wave runs its two blocks one after the other)
+    pl.n_paired = waves == 1 ? nqb : (int)min((int64_t)nqb, (int64_t)pl.chain * (waves - 1));
     pl.n_alone = nqb - pl.n_paired;
     pl.wgs_per_bh = pl.n_alone + (pl.n_paired + 1) / 2;
     return pl;
@@ -207,6 +209,9 @@ __device__ __forceinline__ int udiv_magic(int n, int d, unsigned magic) {
 // kAcquire: the last-arriving workgroup of a split query block runs an agent-scope acquire before it reads the other
 // parts (workspace in a __device__ array: the no-allocation entry point); without it every load of a part is an sc1 load
 // of sc1-stored, drained bytes in hipMalloc memory, one workgroup per CU (MI355X guide, visibility table row 1).
+// kWaves = 1: a workgroup is ONE wave that runs its (up to two) query blocks one after the other, whole -- no split-KV,
+// no shared LDS, no barrier, O straight from the accumulators.  For grids of many rounds: every wave slot of the chip is
+// refilled on its own, and with the pairing n <-> nqb+1-n every wave runs the same nqb+1 units.
 template <int kWaves, int kSegs, bool kAcquire>
 __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         }
         n_seg += seg_n[i] ? 1 : 0;
     }
+    if constexpr (kWaves == 1) active = true;    // (its segments are set up pass by pass below; the masks are not used)
     const int b = udiv_magic(bh, p.num_heads, p.heads_magic), h = bh - b * p.num_heads;
     const int N = p.seq_len;
 
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     //      (Inactive waves and absent segments use zero-record descriptors: no memory touched, no branch.
     //      Giving the query blocks to waves 0-3 only, so that the barrier opens earlier, measured no faster.) ----
     f32x4 kst[8];                    // K staging registers (always one unit ahead of LDS)
+    if constexpr (kWaves > 1) {
     load_unit(unit_rsrc(kg, p.k_rs, u_first * kKeyUnit, N, active), koff, kstep, kst);
     {
         constexpr int kQIters = kSegs * 8 / kWaves;
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     STAMP(122);
     __syncthreads();                 // query blocks complete in LDS
     STAMP(123);
+    }
 
     // O^T accumulators.  MFMA row i of o0 / o1 is d = 2i / 2i+1, so that one dwordx2 per lane fetches both
     // A operands of a PV k-step and each half-wave reads one whole contiguous 256-B V row:
@@ -348,6 +356,18 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     float m_run = -INFINITY;         // running max (log2 domain), same in both lane halves
     float l_run = 0.f;               // running sum over THIS lane half's keys only (merged at the end)
 
+    constexpr int kPasses = kWaves == 1 ? kSegs : 1;     // one-wave workgroups: the segments one after the other
+#pragma unroll 1
+    for (int pass = 0; pass < kPasses; ++pass) {
+    if constexpr (kWaves == 1) {
+        const int n_pass = pass == 0 ? seg_n[0] : seg_n[1];
+        if (n_pass == 0) break;
+        u_first = 0; u_end = n_pass; qb = n_pass - 1; seg_waves = 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+        m_run = -INFINITY;
+        l_run = 0.f;
+    }
     if (active) {
         const int vrs4 = (int)p.v_rs * 4;
         const int voff = half * 4 * vrs4 + l31 * 8;                                       // V: straight into MFMA layout
@@ -366,11 +386,29 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         for (int r = 0; r < 16; ++r) voffs[r] = voff + acc_row(r) * vrs4;
         f32x2 vreg[16];              // V of the current unit, MFMA A-operand layout: [k-step r] = {d even, d odd}
         float qf[32];                // Q^T fragment: B operand of S^T = K Q^T; k-step 4c+j uses d = 8c + 4*half + j
+        if constexpr (kWaves == 1) {
+            // this pass's first K unit and the query block's fragments straight from global memory in operand layout
+            // (lane = query: eight 16-B pieces of its row), one round trip for both
+            load_unit(unit_rsrc(kg, p.k_rs, 0, N), koff, kstep, kst);
+            const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, qb * kQBlock, N);
+            f32x4 qt[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                qt[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (l31 * (int)p.q_rs + 8 * c + 4 * half) * 4, 0, 0));
+            store_unit<true>(wlds, lane, kst);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qf[4 * c + j] = qt[c][j] * kScaleLog2;
+        } else {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const f32x4 t = *reinterpret_cast<const f32x4 *>(qlds + l31 * kHeadDim + (((2 * c + half) ^ sw) << 2));
 #pragma unroll
             for (int j = 0; j < 4; ++j) qf[4 * c + j] = t[j];
+        }
         }
         f32x4 kcur = kfrag(0), knext = kfrag(1);
         STAMP(1);
@@ -516,10 +554,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         unit(u_first, std::true_type{});         // every active wave owns at least one unit (a segment has no more waves than units)
         for (int u = u_first + seg_waves; u < u_end; u += seg_waves) unit(u, std::false_type{});
         l_run = xhalf_sum(l_run);
+        if constexpr (kWaves == 1) {
+            // the whole block was this wave's: normalise and store, lane = query, 4 consecutive d per store (the merge's pairs)
+            __builtin_amdgcn_s_setprio(0);
+            const float inv = 1.0f / l_run;
+            float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
+            const int row = qb * kQBlock + l31;
+#pragma unroll
+            for (int pi = 0; pi < 8; ++pi) {
+                const f32x4 t = {o0[2 * pi], o1[2 * pi], o0[2 * pi + 1], o1[2 * pi + 1]};
+                const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);
+                store_o(og + (int64_t)row * p.o_rs + col, t * inv, row < N);
+            }
+        }
     }
+    }   // pass
 #ifdef CMHSA_STAMPS
     STAMP(2);
 #endif
+    if constexpr (kWaves > 1) {
 
     // ---- merge the split-KV partials of each segment: ONE barrier, no transposition.
     //      Every active wave publishes its un-normalised O accumulators in their native MFMA layout, as 8
@@ -674,20 +727,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             }
         }
     }
+    }   // kWaves > 1
 #ifdef CMHSA_STAMPS
     STAMP(3);
     if (g_block_times && threadIdx.x == 0) g_block_times[2 * lin_block + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
-std::atomic<int> g_attr_set[5][64];  // per variant and device: dynamic-LDS limit raised once, not per call
+std::atomic<int> g_attr_set[6][64];  // per variant and device: dynamic-LDS limit raised once, not per call
 
 template <int kWaves, int kSegs, bool kAcquire>
 hipError_t launch(const Params &p, dim3 grid, void *stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kAcquire ? 4 : (kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
+    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kWaves == 1 ? 5 : kAcquire ? 4 : (kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
     if (!flag || !flag->load(std::memory_order_acquire)) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs, kAcquire>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kWaves, kSegs));
@@ -822,7 +876,8 @@ void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
 }
 
 // Experiments only (tests/helpers/libcmhsa_hip_planenv.so and tools/ build the library with -DCMHSA_PLAN_ENV):
-// CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force an analytic / chain plan, CMHSA_PACKED=L forces a packed plan
+// CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force an analytic / chain plan, CMHSA_WAVES=1 one-wave workgroups
+// (CMHSA_NOWP=1: never those), CMHSA_PACKED=L forces a packed plan
 // with SIMD cap L (CMHSA_SPLIT=0|1: without / with blocks split across workgroups), CMHSA_VERBOSE prints the choice.
 // The shipped library reads no environment variable.
 #ifdef CMHSA_PLAN_ENV
@@ -1089,19 +1144,41 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
             }
         }
     }
-    // the default for grids of several rounds: the analytic plan with 4-wave workgroups at the smallest c, two workgroups
-    // per CU.  Priced as (rounds + a quarter for the tail) x (kFixed + the 2 c units a SIMD runs for its two workgroups):
-    // B=4, H=12, T=1024 measures 68.8 us so (est. 174 k cycles) against 79.8 us for the best single-round candidate (a
-    // chain table with c = 24), B=16 248 us (est. 635 k cycles).
+    // Grids of several rounds.  Two families, each priced from a fit to measured launch times (cycles at 2.4 GHz; both
+    // fits within 5 % on the 15 shapes of tools/run_w1.sh, B*H = 16..1600, T = 256..8192):
+    //   (a) the analytic plan with 4-wave workgroups at the smallest c, two workgroups per CU:
+    //           (rounds + 1/4 for the tail) x (12 k + 8 k * c)        rounds = workgroups / (2 * CUs)
+    //       e.g. B=4, H=12, T=1024: 68.8 us against 79.8 us for the best single-round candidate (a chain table, c = 24);
+    //   (b) ONE-WAVE workgroups, each running the pair n <-> nqb+1-n whole (nqb+1 units): every wave slot (two per SIMD)
+    //       is refilled on its own, every job is equally long, and no wave waits at a workgroup's merge barrier for a
+    //       sibling that shares its SIMD with a slower neighbour (what holds (a) to ~80 % of the MFMA peak on long
+    //       sequences: BASELINE config 5's shard 1108 us under (a), 978 us = 89 % under (b)):
+    //           (whole rounds + partial) x (16 k + 9.2 k * (nqb + 1))   rounds = jobs / (8 * CUs),
+    //       where a partial round of fill f costs min(1, 1/2 + 3/2 f) of a whole one (the dispatcher does not spread the
+    //       stragglers one per SIMD).  (b) wins when the jobs fill the wave slots a whole number of times, or many times.
     {
         Plan multi;
         multi.pp = pack_plan(nqb, 4);
         multi.use_table = false;
         multi.n_wgs = multi.pp.wgs_per_bh;
         const double rounds = (double)bh * multi.n_wgs / (2.0 * cus);
-        multi.cycles = (fmax(rounds, 1.0) + 0.25) * (kFixedCycles + 2.0 * multi.pp.chain * kUnitCycles);
+        multi.cycles = (fmax(rounds, 1.0) + 0.25) * (12000.0 + 8000.0 * multi.pp.chain);
         multi.family = "analytic, several rounds";
         if (!have || (rounds > 1.0 && !forced_old && !forced_packed && multi.cycles < best.cycles * 0.98)) { best = multi; have = true; }
+    }
+    {
+        Plan wp;
+        wp.pp = pack_plan(nqb, 1);
+        wp.use_table = false;
+        wp.n_wgs = wp.pp.wgs_per_bh;
+        const double rounds = (double)bh * wp.n_wgs / (8.0 * cus), whole = floor(rounds + 0.02), f = fmax(0.0, rounds - whole);
+        wp.cycles = (whole + (f > 0.02 ? fmin(1.0, 0.5 + 1.5 * f) : 0.0)) * (16000.0 + 9200.0 * (nqb + 1));
+        wp.family = "one wave per pair of query blocks";
+        static const int no_wave_pairs = env_int("CMHSA_NOWP", 0);
+        if (forced_waves == 1 || (!no_wave_pairs && rounds > 0.98 && !forced_old && !forced_packed && have && wp.cycles < best.cycles * 0.97)) {
+            best = wp;
+            have = true;
+        }
     }
     static const bool verbose = env_int("CMHSA_VERBOSE", 0) != 0;
     if (verbose)
@@ -1317,7 +1394,8 @@ int forward(const float *q, const float *k, const float *v, float *o,
     if (plan.use_table) memcpy(p.seg_table, plan.table, sizeof(unsigned) * (size_t)plan.n_wgs * kTableWords);
 
     hipError_t e;
-    if (!p.use_table) e = waves == 8 ? launch<8, 2, false>(p, grid, stream) : launch<4, 2, false>(p, grid, stream);
+    if (waves == 1) e = launch<1, 2, false>(p, grid, stream);
+    else if (!p.use_table) e = waves == 8 ? launch<8, 2, false>(p, grid, stream) : launch<4, 2, false>(p, grid, stream);
     else if (waves == 4) e = launch<4, 4, false>(p, grid, stream);
     else e = split && acquire ? launch<8, 4, true>(p, grid, stream) : launch<8, 4, false>(p, grid, stream);
     return e == hipSuccess ? CMHSA_OK : (int)e;     // launch-configuration errors only; no synchronisation (CMHSA.cu:450)

@@ -305,6 +305,28 @@ def test_config4_attention_shape_gpt2_xl(B, gpu_device):
         assert np.abs(oc[b, :, sl] - want).max() <= TOL, (b, h)
 
 
+@pytest.mark.parametrize("B,H,T", [(16, 16, 512), (16, 16, 500), (16, 16, 480), (16, 16, 449), (4, 16, 2048), (85, 3, 490)])
+def test_one_wave_workgroup_plans(B, H, T, gpu_device):
+    """Grids of several rounds whose jobs fill the chip's wave slots get ONE-WAVE workgroups: a wave runs the query
+    blocks n and nqb+1-n one after the other, whole, and writes O straight from its accumulators (no LDS merge).
+    Exact and ragged lengths, an odd number of query blocks (the middle one has no partner), B*H not a multiple of 8
+    (no XCD-pinned grid): every element written, the whole output against the oracle's formula in float64, batch rows of
+    equal inputs bit-identical, strided (packed-QKV) inputs."""
+    assert "one wave per pair" in cmhsa.plan_description(B, T, H), cmhsa.plan_description(B, T, H)
+    torch.manual_seed(B * 1000 + T)
+    d = 64 * H
+    qkv = torch.randn(B, T, 3 * d, device=gpu_device)
+    qkv[B - 1] = qkv[0]
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    out = torch.full((B, T, d), float("nan"), device=gpu_device)
+    cmhsa.attention_fwd(q, k, v, H, out=out)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out[0], out[B - 1])
+    want = oracle.naive_attention_torch(q.double(), k.double(), v.double(), H)
+    assert (out.double() - want).abs().max().item() <= TOL
+    assert torch.equal(cmhsa.attention_fwd(q, k, v, H), out)          # and again: bit-reproducible
+
+
 @pytest.mark.gpu
 def test_packed_qkv_entry_point_equals_the_three_view_call(gpu_device):
     """one packed (.., T, 3*d_model) buffer in -- same kernel, so the same bits as slicing it into
@@ -374,7 +396,8 @@ def test_long_sequences_spot_rows_against_f64(gpu_device, T, H):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"CMHSA_TABLE": "1", "CMHSA_WAVES": "8"}, {"CMHSA_TABLE": "1", "CMHSA_WAVES": "4"},
                                  {"CMHSA_TABLE": "1", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "9"},
-                                 {"CMHSA_TABLE": "0", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "7"}])
+                                 {"CMHSA_TABLE": "0", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "7"},
+                                 {"CMHSA_WAVES": "1"}])
 def test_forced_plans_in_a_child_process(env):
     """The plan (workgroup shape, chain cap, analytic or table packing with up to four query blocks per workgroup) is
     chosen per shape by a cost model.  The shipped library reads no environment variable; the TEST build of the same
