@@ -356,17 +356,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     float m_run = -INFINITY;         // running max (log2 domain), same in both lane halves
     float l_run = 0.f;               // running sum over THIS lane half's keys only (merged at the end)
 
-    constexpr int kPasses = kWaves == 1 ? kSegs : 1;     // one-wave workgroups: the segments one after the other
-#pragma unroll 1
-    for (int pass = 0; pass < kPasses; ++pass) {
+    // one-wave workgroups: the wave runs segment 0 whole, then segment 1 (n_after units; 0 = none).  Its K/V prefetch
+    // stream runs on ACROSS the boundary: the units after the last one of a block are the first ones of the next.
+    int n_after = 0;
     if constexpr (kWaves == 1) {
-        const int n_pass = pass == 0 ? seg_n[0] : seg_n[1];
-        if (n_pass == 0) break;
-        u_first = 0; u_end = n_pass; qb = n_pass - 1; seg_waves = 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-        m_run = -INFINITY;
-        l_run = 0.f;
+        u_first = 0; u_end = seg_n[0]; qb = u_end - 1; seg_waves = 1;
+        n_after = seg_n[1];
     }
     if (active) {
         const int vrs4 = (int)p.v_rs * 4;
@@ -413,6 +408,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         f32x4 kcur = kfrag(0), knext = kfrag(1);
         STAMP(1);
 
+        // descriptor of the unit this wave processes d steps after unit u (zero records when there is none).  One-wave
+        // workgroups: past the end of the block it is a unit of the wave's NEXT block.
+        auto ahead = [&](const float *base, int64_t rs, int u, int d) {
+            int t = u + d * seg_waves;
+            bool en = t < u_end;
+            if constexpr (kWaves == 1) {
+                if (!en) { t -= u_end; en = t < n_after; }
+            }
+            return unit_rsrc(base, rs, t * kKeyUnit, N, en);
+        };
+
         // One unit = QK chain, softmax, PV chain.  `first` (compile time): the wave's first unit, whose QK chain
         // also carries the loads the steady state issues one unit ahead -- V(u) and K(u + seg_waves) -- so that
         // the first MFMA does not queue behind 24 more buffer loads per wave (a CU's L1 serves 64 B/clk).
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             __amdgpu_buffer_rsrc_t vsrc0, ksrc1;
             if constexpr (kFirst) {
                 vsrc0 = unit_rsrc(vg, p.v_rs, u * kKeyUnit, N);
-                ksrc1 = unit_rsrc(kg, p.k_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < u_end);
+                ksrc1 = ahead(kg, p.k_rs, u, 1);
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -520,8 +526,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             //        steps 8-15 : K(u+2) global -> staging registers;  steps 13,14: first K(u+1) fragments ----
             //      Everything is unconditional (past the last unit the descriptors have zero records and the
             //      LDS unit receives zeros nobody reads), so the chain stays one basic block.
-            const __amdgpu_buffer_rsrc_t ksrc2 = unit_rsrc(kg, p.k_rs, (u + 2 * seg_waves) * kKeyUnit, N, u + 2 * seg_waves < u_end);
-            const __amdgpu_buffer_rsrc_t vsrc1 = unit_rsrc(vg, p.v_rs, (u + seg_waves) * kKeyUnit, N, u + seg_waves < u_end);
+            const __amdgpu_buffer_rsrc_t ksrc2 = ahead(kg, p.k_rs, u, 2);
+            const __amdgpu_buffer_rsrc_t vsrc1 = ahead(vg, p.v_rs, u, 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (r < 8) {
@@ -552,23 +558,47 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 
         __builtin_amdgcn_s_setprio(2);
         unit(u_first, std::true_type{});         // every active wave owns at least one unit (a segment has no more waves than units)
-        for (int u = u_first + seg_waves; u < u_end; u += seg_waves) unit(u, std::false_type{});
-        l_run = xhalf_sum(l_run);
-        if constexpr (kWaves == 1) {
-            // the whole block was this wave's: normalise and store, lane = query, 4 consecutive d per store (the merge's pairs)
-            __builtin_amdgcn_s_setprio(0);
-            const float inv = 1.0f / l_run;
+        if constexpr (kWaves > 1) {
+            for (int u = u_first + seg_waves; u < u_end; u += seg_waves) unit(u, std::false_type{});
+            l_run = xhalf_sum(l_run);
+        } else {
             float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
-            const int row = qb * kQBlock + l31;
+            int u = 1;
+            for (;;) {
+                for (; u < u_end; ++u) unit(u, std::false_type{});
+                // the whole block was this wave's: normalise and store, lane = query, 4 consecutive d per store (the
+                // merge's pairs).  The next block's first K unit is in LDS and its first V unit in flight already; its
+                // query fragments are requested BEFORE the stores (the registers of this block's are free now)
+                const int n_next = n_after;
+                f32x4 qt[8];
+                if (n_next) {
+                    const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, (n_next - 1) * kQBlock, N);
 #pragma unroll
-            for (int pi = 0; pi < 8; ++pi) {
-                const f32x4 t = {o0[2 * pi], o1[2 * pi], o0[2 * pi + 1], o1[2 * pi + 1]};
-                const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);
-                store_o(og + (int64_t)row * p.o_rs + col, t * inv, row < N);
+                    for (int c = 0; c < 8; ++c)
+                        qt[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (l31 * (int)p.q_rs + 8 * c + 4 * half) * 4, 0, 0));
+                }
+                const float inv = 1.0f / xhalf_sum(l_run);
+                const int row = qb * kQBlock + l31;
+#pragma unroll
+                for (int pi = 0; pi < 8; ++pi) {
+                    const f32x4 t = {o0[2 * pi], o1[2 * pi], o0[2 * pi + 1], o1[2 * pi + 1]};
+                    const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);
+                    store_o(og + (int64_t)row * p.o_rs + col, t * inv, row < N);
+                }
+                if (!n_next) break;
+                // fresh accumulators; m_run = -inf sends the block's first unit down the max path (its row sums are not finite)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+                m_run = -INFINITY;
+                l_run = 0.f;
+                u_end = n_next; qb = n_next - 1; n_after = 0; u = 0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qf[4 * c + j] = qt[c][j] * kScaleLog2;
             }
         }
     }
-    }   // pass
 #ifdef CMHSA_STAMPS
     STAMP(2);
 #endif
