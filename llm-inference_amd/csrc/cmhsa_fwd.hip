@@ -105,6 +105,7 @@ struct Params {
     int num_heads;                      // H
     int nqb;                            // ceil(N / 32)
     int grid_x;                         // gridDim.x: 8 when (b,h)s are pinned to XCDs, else bh (see the kernel)
+    int bh_count;                       // B*H (one-wave workgroups, longest-first grid: gridDim.x is B*H rounded up to 8)
     unsigned heads_magic, chain_magic;  // floor((2^32-1) / num_heads), floor((2^32-1) / chain): udiv_magic()
     // packing of query blocks into workgroups (pack_plan()):
     int chain;                          // c: max units any wave processes (>= ceil(nqb / kWaves))
@@ -250,6 +251,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     //      stay in that XCD's L2), with grid = (bh, wgs_per_bh, 1) otherwise; either way j = 0 (heaviest) first.
     const int bh = blockIdx.z * p.grid_x + blockIdx.x;
     const int j = blockIdx.y;
+    if constexpr (kWaves == 1) {
+        if (bh >= p.bh_count) return;            // padding of the longest-first grid (no barrier in this variant)
+    }
     // ---- workgroup j -> up to kSegs query blocks ("segments"), this wave -> (segment, local wave index) ----
     int seg_n[kSegs];                           // units (= query block index + 1) of each segment's query block; 0 = none
     int seg_ulo[kSegs], seg_cnt[kSegs];          // the segment covers units [ulo, ulo + cnt) of it (the whole block: 0, n)
@@ -812,6 +816,7 @@ struct Plan {
     int parts_per_bh = 0, splits_per_bh = 0;     // > 0: some blocks are split across workgroups (needs a workspace)
     int simd_cap = 0;                            // packed plans: L
     bool single_round = false;                   // the whole grid is resident at once
+    int longest_first = 0;                       // G > 0: one-wave workgroups, one block each; (b,h)s in groups of G (a multiple of 8), within a group longest blocks first
     double cycles = 0.0;
     const char *family = "analytic";
     unsigned table[kMaxTableWgs * kTableWords];  // table plans: Params::seg_table
@@ -907,7 +912,8 @@ void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
 
 // Experiments only (tests/helpers/libcmhsa_hip_planenv.so and tools/ build the library with -DCMHSA_PLAN_ENV):
 // CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force an analytic / chain plan, CMHSA_WAVES=1 one-wave workgroups
-// (CMHSA_NOWP=1: never those), CMHSA_PACKED=L forces a packed plan
+// (CMHSA_NOWP=1: never those; CMHSA_LPT=0: pairs of blocks only, CMHSA_LPT=G: one block per wave, longest first in groups
+// of G (b,h)s), CMHSA_PACKED=L forces a packed plan
 // with SIMD cap L (CMHSA_SPLIT=0|1: without / with blocks split across workgroups), CMHSA_VERBOSE prints the choice.
 // The shipped library reads no environment variable.
 #ifdef CMHSA_PLAN_ENV
@@ -1196,6 +1202,9 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
         multi.family = "analytic, several rounds";
         if (!have || (rounds > 1.0 && !forced_old && !forced_packed && multi.cycles < best.cycles * 0.98)) { best = multi; have = true; }
     }
+    static const int no_one_wave = env_int("CMHSA_NOWP", 0);
+    static const int forced_lpt = env_int("CMHSA_LPT", -1);      // -1 = planner's choice, 0 = pairs only, G > 0: longest first in groups of G
+    const bool multi_ok = !forced_old && !forced_packed && have;
     {
         Plan wp;
         wp.pp = pack_plan(nqb, 1);
@@ -1203,10 +1212,42 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
         wp.n_wgs = wp.pp.wgs_per_bh;
         const double rounds = (double)bh * wp.n_wgs / (8.0 * cus), whole = floor(rounds + 0.02), f = fmax(0.0, rounds - whole);
         wp.cycles = (whole + (f > 0.02 ? fmin(1.0, 0.5 + 1.5 * f) : 0.0)) * (16000.0 + 9200.0 * (nqb + 1));
+        // less than half a round: the first jobs are spread one per SIMD and run alone (5 k cycles per unit; B=5 H=12 T=1024:
+        // 73 us against 91 us for the analytic plan)
+        if (whole == 0.0 && f <= 0.5) wp.cycles = 10000.0 + 5000.0 * (nqb + 1);
         wp.family = "one wave per pair of query blocks";
-        static const int no_wave_pairs = env_int("CMHSA_NOWP", 0);
-        if (forced_waves == 1 || (!no_wave_pairs && rounds > 0.98 && !forced_old && !forced_packed && have && wp.cycles < best.cycles * 0.97)) {
+        if ((forced_waves == 1 && forced_lpt <= 0) ||
+            (!no_one_wave && forced_lpt <= 0 && rounds > 0.3 && multi_ok && wp.cycles < best.cycles * 0.97)) {
             best = wp;
+            have = true;
+        }
+    }
+    //   (c) one-wave workgroups with ONE block each, dispatched longest first across ALL (b,h)s (grid x = (b,h) padded to a
+    //       multiple of 8, so that a (b,h) stays on one XCD; y = block, longest first): the hardware's in-order dispatch
+    //       onto whichever wave slot frees up is then longest-processing-time-first list scheduling -- no round
+    //       quantisation, the tail is made of 1-unit jobs.  The jobs of a (b,h) that start together stream the same K/V
+    //       units almost in step (L2 hits), but every (b,h) is live at once: only while all K and V fit the 256 MB
+    //       infinity cache with room to spare (measured: B=64 H=25 T=512, 420 MB: +22 %; B=16 H=12 T=1024, 100 MB: -15 %).
+    //           max( 15 k + 9.8 k * units per wave slot + 8 k * jobs per wave slot,  8 k + u * nqb )
+    //       u = 9.2 k cycles per unit for the longest job, less when there are under two jobs per slot (its SIMD neighbour
+    //       runs out of work: 8.5 k at 1.5 jobs per slot, measured)
+    {
+        Plan lf;
+        lf.pp = pack_plan(nqb, 1);
+        lf.pp.n_paired = 0;
+        lf.pp.n_alone = nqb;
+        lf.pp.wgs_per_bh = lf.n_wgs = nqb;
+        lf.use_table = false;
+        const int64_t bh_pad = (bh + 7) / 8 * 8;
+        lf.longest_first = (int)min(bh_pad, forced_lpt > 0 ? (int64_t)(forced_lpt + 7) / 8 * 8 : bh_pad);
+        const double slots = 8.0 * cus, units = (double)bh_pad * nqb * (nqb + 1) / 2 / slots, jobs = (double)bh_pad * nqb / slots;
+        const double longest_unit = jobs >= 2.0 ? 9200.0 : 5000.0 + 4200.0 * fmin(1.0, fmax(0.0, (jobs - 0.5) / 1.2));
+        lf.cycles = fmax(15000.0 + 9800.0 * units + 8000.0 * jobs, 8000.0 + longest_unit * nqb);
+        lf.family = "one wave per query block, longest first";
+        const bool fits_cache = (double)bh * nqb * kQBlock * 512.0 <= 208e6 && bh_pad <= 0x7fffffff;
+        if ((forced_waves == 1 && forced_lpt > 0) ||
+            (!no_one_wave && forced_lpt < 0 && fits_cache && jobs > 0.98 && multi_ok && lf.cycles < best.cycles * 0.97)) {
+            best = lf;
             have = true;
         }
     }
@@ -1399,8 +1440,12 @@ int forward(const float *q, const float *k, const float *v, float *o,
     const int waves = pl.waves;
     // grid = (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8
     // or too large for gridDim.z.  HIP limits: y, z <= 65535, and x * threads < 2^32.
-    const bool xcd_map = bh % 8 == 0 && bh / 8 <= 65535;
-    const dim3 grid(xcd_map ? 8u : (unsigned)bh, (unsigned)pl.wgs_per_bh, xcd_map ? (unsigned)(bh / 8) : 1u);
+    const bool xcd_map = bh % 8 == 0 && bh / 8 <= 65535 && !plan.longest_first;
+    // (longest first: x = (b,h), padded to a multiple of 8 so that a (b,h) stays on one XCD; y = block, longest first)
+    const int64_t lf_groups = plan.longest_first ? (bh + plan.longest_first - 1) / plan.longest_first : 0;
+    if (lf_groups > 65535) return CMHSA_ERR_TOO_LARGE;
+    const dim3 grid(plan.longest_first ? (unsigned)plan.longest_first : xcd_map ? 8u : (unsigned)bh, (unsigned)pl.wgs_per_bh,
+                    plan.longest_first ? (unsigned)lf_groups : xcd_map ? (unsigned)(bh / 8) : 1u);
     if (pl.wgs_per_bh > 65535 || (int64_t)grid.x * (waves * 64) >= (1LL << 32) ||
         bh * pl.wgs_per_bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
 
@@ -1412,6 +1457,7 @@ int forward(const float *q, const float *k, const float *v, float *o,
     p.num_heads = num_heads;
     p.nqb = (int)nqb;
     p.grid_x = (int)grid.x;
+    p.bh_count = (int)bh;
     p.heads_magic = 0xffffffffu / (unsigned)num_heads;
     p.chain_magic = 0xffffffffu / (unsigned)pl.chain;
     p.chain = pl.chain; p.n_paired = pl.n_paired; p.n_alone = pl.n_alone;

@@ -305,14 +305,22 @@ def test_config4_attention_shape_gpt2_xl(B, gpu_device):
         assert np.abs(oc[b, :, sl] - want).max() <= TOL, (b, h)
 
 
-@pytest.mark.parametrize("B,H,T", [(16, 16, 512), (16, 16, 500), (16, 16, 480), (16, 16, 449), (4, 16, 2048), (85, 3, 490)])
-def test_one_wave_workgroup_plans(B, H, T, gpu_device):
-    """Grids of several rounds whose jobs fill the chip's wave slots get ONE-WAVE workgroups: a wave runs the query
-    blocks n and nqb+1-n one after the other, whole, and writes O straight from its accumulators (no LDS merge).
-    Exact and ragged lengths, an odd number of query blocks (the middle one has no partner), B*H not a multiple of 8
-    (no XCD-pinned grid): every element written, the whole output against the oracle's formula in float64, batch rows of
-    equal inputs bit-identical, strided (packed-QKV) inputs."""
-    assert "one wave per pair" in cmhsa.plan_description(B, T, H), cmhsa.plan_description(B, T, H)
+PAIRS, LONGEST_FIRST = "one wave per pair of query blocks", "one wave per query block, longest first"
+
+
+@pytest.mark.parametrize("B,H,T,family", [(16, 16, 512, PAIRS), (16, 16, 500, PAIRS), (16, 16, 480, PAIRS), (16, 16, 449, PAIRS),
+                                          (4, 16, 2048, PAIRS), (85, 3, 490, PAIRS), (5, 12, 1001, PAIRS),
+                                          (16, 12, 500, LONGEST_FIRST), (8, 25, 512, LONGEST_FIRST), (7, 25, 600, LONGEST_FIRST),
+                                          (21, 9, 1000, LONGEST_FIRST), (16, 12, 1024, LONGEST_FIRST)])
+def test_one_wave_workgroup_plans(B, H, T, family, gpu_device):
+    """Larger grids get ONE-WAVE workgroups: a wave runs whole query blocks (no split-KV, no LDS merge) and writes O
+    straight from its accumulators -- either the pair n and nqb+1-n one after the other (equal jobs; the prefetch stream
+    runs on across the two blocks), or one block per wave with the grid ordered longest block first across all (b,h)s
+    (grid x = B*H padded to a multiple of 8: the padding workgroups must exit).  Exact and ragged lengths, an odd number
+    of query blocks (the middle one has no partner), B*H not a multiple of 8, under half a round of jobs: every element
+    written, the whole output against the oracle's formula in float64, batch rows of equal inputs bit-identical, strided
+    (packed-QKV) inputs, bit-reproducible."""
+    assert cmhsa.plan_description(B, T, H).startswith(family + ":"), cmhsa.plan_description(B, T, H)
     torch.manual_seed(B * 1000 + T)
     d = 64 * H
     qkv = torch.randn(B, T, 3 * d, device=gpu_device)
@@ -397,7 +405,7 @@ def test_long_sequences_spot_rows_against_f64(gpu_device, T, H):
 @pytest.mark.parametrize("env", [{"CMHSA_TABLE": "1", "CMHSA_WAVES": "8"}, {"CMHSA_TABLE": "1", "CMHSA_WAVES": "4"},
                                  {"CMHSA_TABLE": "1", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "9"},
                                  {"CMHSA_TABLE": "0", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "7"},
-                                 {"CMHSA_WAVES": "1"}])
+                                 {"CMHSA_WAVES": "1"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "16"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "1000000"}])
 def test_forced_plans_in_a_child_process(env):
     """The plan (workgroup shape, chain cap, analytic or table packing with up to four query blocks per workgroup) is
     chosen per shape by a cost model.  The shipped library reads no environment variable; the TEST build of the same
