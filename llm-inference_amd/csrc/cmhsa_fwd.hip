@@ -328,7 +328,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     //      (Inactive waves and absent segments use zero-record descriptors: no memory touched, no branch.
     //      Giving the query blocks to waves 0-3 only, so that the barrier opens earlier, measured no faster.) ----
     f32x4 kst[8];                    // K staging registers (always one unit ahead of LDS)
-    if constexpr (kWaves > 1) {
+    // (one-wave workgroups fetch their query fragments straight from global memory, below.  The same in 8-wave
+    //  workgroups -- no staging, no barrier here -- measured +0.6 us on BASELINE config 2: 64 strided 16-B pieces per load)
+    constexpr bool kDirectQ = kWaves == 1;
+    if constexpr (!kDirectQ) {
     load_unit(unit_rsrc(kg, p.k_rs, u_first * kKeyUnit, N, active), koff, kstep, kst);
     {
         constexpr int kQIters = kSegs * 8 / kWaves;
@@ -385,10 +388,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         for (int r = 0; r < 16; ++r) voffs[r] = voff + acc_row(r) * vrs4;
         f32x2 vreg[16];              // V of the current unit, MFMA A-operand layout: [k-step r] = {d even, d odd}
         float qf[32];                // Q^T fragment: B operand of S^T = K Q^T; k-step 4c+j uses d = 8c + 4*half + j
-        if constexpr (kWaves == 1) {
+        if constexpr (kDirectQ) {
             // this pass's first K unit and the query block's fragments straight from global memory in operand layout
             // (lane = query: eight 16-B pieces of its row), one round trip for both
-            load_unit(unit_rsrc(kg, p.k_rs, 0, N), koff, kstep, kst);
+            load_unit(unit_rsrc(kg, p.k_rs, u_first * kKeyUnit, N), koff, kstep, kst);
             const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, qb * kQBlock, N);
             f32x4 qt[8];
 #pragma unroll
