@@ -119,6 +119,20 @@ size_t cmhsa_fp32_fwd_workspace_bytes(int batch, int seq_len, int num_heads);
  * with a full-size workspace (1) uses for this shape on the current device into buf (NUL-terminated). */
 int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspace, char *buf, int buf_len);
 
+/* Diagnostics / tests (no reference counterpart; touches no GPU when cus > 0): the whole plan of a shape as integers, so
+ * that a host-side test can check that every 32-key unit of every 32-row query block is computed exactly once.
+ * `cus` = compute units to plan for (0: the current device's).  Returns the number of ints the dump needs (> 0; nothing
+ * is written when out is NULL or cap is smaller) or a negative CMHSA_ERR_*.  Layout:
+ *   out[0..15]  waves per workgroup | segments per record (2 or 4) | workgroups per (b,h) | grid x | y | z |
+ *               part slots per (b,h) | split blocks per (b,h) | SIMD cap | query blocks | table plan? |
+ *               longest-first group size (0 = no) | chain cap | n_paired | n_alone | workspace bytes / 256
+ *   then per workgroup j of a (b,h), per segment: n (units of the query block = block index + 1; 0 = absent) |
+ *               first unit | unit count | wave mask | part word (0 = whole block, else first part slot | part index << 8 |
+ *               parts << 12 | split id << 16).
+ * The waves of a segment's mask take its units round-robin in ascending wave order; one-wave workgroups run their
+ * segments one after the other, whole. */
+int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, int cus, int *out, int cap);
+
 /* Convenience form of the reference's exact contract: 2-D (N, d_model) tensors, batch 1
  * (CMHSA.cu:476-478, :488-489, :500-512).  Equivalent to cmhsa_fp32_fwd(..., batch = 1). */
 int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "cmhsa_workspace_init",
     "cmhsa_fp32_fwd_workspace_bytes",
     "cmhsa_plan_describe",
+    "cmhsa_plan_dump",
     "cmhsa_fp32_fwd_2d",
     "cmhsa_fp32_fwd_packed_qkv",
     "cmhsa_fp32_decode_step",
@@ -93,6 +94,8 @@ def load_library() -> ctypes.CDLL:
     lib.cmhsa_fp32_fwd_workspace_bytes.argtypes = [i32, i32, i32]
     lib.cmhsa_plan_describe.restype = i32
     lib.cmhsa_plan_describe.argtypes = [i32, i32, i32, i32, ctypes.c_char_p, i32]
+    lib.cmhsa_plan_dump.restype = i32
+    lib.cmhsa_plan_dump.argtypes = [i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int), i32]
     lib.cmhsa_fp32_fwd_2d.restype = i32
     lib.cmhsa_fp32_fwd_2d.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp]
     lib.cmhsa_fp32_fwd_packed_qkv.restype = i32
@@ -120,6 +123,26 @@ def status_string(status: int) -> str:
 def algorithmic_flops(batch: int, seq_len: int, num_heads: int, head_dim: int = 64) -> float:
     """F = 2*B*H*d*T*(T+1); pure host arithmetic, no GPU needed."""
     return float(load_library().cmhsa_algorithmic_flops(batch, seq_len, num_heads, head_dim))
+
+
+def plan_dump(batch: int, seq_len: int, num_heads: int, with_workspace: bool = False, cus: int = 0) -> dict:
+    """The plan of a shape as data (cmhsa_plan_dump; no GPU needed when `cus` is given): header fields and, per workgroup
+    of a (b,h), its segments as (n, first_unit, unit_count, wave_mask, part_word) tuples (absent segments dropped)."""
+    lib = load_library()
+    need = lib.cmhsa_plan_dump(batch, seq_len, num_heads, 1 if with_workspace else 0, cus, None, 0)
+    if need <= 0:
+        raise CmhsaError(need, status_string(need))
+    buf = (ctypes.c_int * need)()
+    got = lib.cmhsa_plan_dump(batch, seq_len, num_heads, 1 if with_workspace else 0, cus, buf, need)
+    if got != need:
+        raise CmhsaError(got, status_string(got))
+    names = ("waves", "segs", "wgs_per_bh", "grid_x", "grid_y", "grid_z", "parts_per_bh", "splits_per_bh", "simd_cap", "nqb",
+             "use_table", "longest_first", "chain", "n_paired", "n_alone", "workspace_256")
+    plan = dict(zip(names, buf[:16]))
+    segs = plan["segs"]
+    plan["workgroups"] = [[tuple(buf[16 + (j * segs + i) * 5: 16 + (j * segs + i) * 5 + 5]) for i in range(segs)
+                           if buf[16 + (j * segs + i) * 5] != 0] for j in range(plan["wgs_per_bh"])]
+    return plan
 
 
 def plan_description(batch: int, seq_len: int, num_heads: int, workspace_bytes: int = 0) -> str:

@@ -201,9 +201,55 @@ __device__ __forceinline__ void store_o(float *ptr, f32x4 v, bool in_range) {
 // floor(n / d) for wave-uniform n, d >= 1 with magic = floor((2^32 - 1) / d): the estimate mulhi(n, magic) is
 // the quotient or one below it for every 32-bit n, so one correction step makes it exact.  A handful of
 // scalar instructions instead of the ~30-instruction float-reciprocal sequence hipcc emits for `/`.
-__device__ __forceinline__ int udiv_magic(int n, int d, unsigned magic) {
+__host__ __device__ __forceinline__ int udiv_magic(int n, int d, unsigned magic) {
+#if defined(__HIP_DEVICE_COMPILE__)
     const unsigned q = __umulhi((unsigned)n, magic);
+#else
+    const unsigned q = (unsigned)(((uint64_t)(unsigned)n * magic) >> 32);
+#endif
     return (int)(q + (((unsigned)n - q * (unsigned)d) >= (unsigned)d ? 1u : 0u));
+}
+
+// Workgroup j of a (b,h) -> its segments.  ONE definition for the kernel and for the host (cmhsa_plan_dump(), which the
+// CPU tests use to check that every plan covers every unit of every query block exactly once).
+//   kSegs > 2: explicit plan, `tw` = the workgroup's eight table words (Params::seg_table);
+//   else the analytic plan: the n_alone longest blocks alone, the others paired n <-> n_paired+1-n (the middle block of an
+//   odd count alone); a block with n units gets ceil(n / chain) consecutive waves.
+template <int kSegs>
+__host__ __device__ __forceinline__ void decode_segments(const unsigned *tw, int j, int nqb, int n_paired, int n_alone, int chain,
+                                                         unsigned chain_magic, int (&seg_n)[kSegs], int (&seg_ulo)[kSegs],
+                                                         int (&seg_cnt)[kSegs], unsigned (&seg_mask)[kSegs], unsigned (&seg_x)[kSegs]) {
+    if (kSegs > 2) {
+#pragma unroll
+        for (int i = 0; i < kSegs; ++i) {
+            const unsigned w0 = tw[2 * i];
+            seg_n[i] = w0 & 255;
+            seg_ulo[i] = (w0 >> 8) & 255;
+            seg_cnt[i] = (w0 >> 16) & 255;
+            seg_mask[i] = w0 >> 24;
+            seg_x[i] = tw[2 * i + 1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kSegs; ++i) seg_n[i] = 0;
+        if (j < n_alone) {
+            seg_n[0] = nqb - j;
+        } else {
+            const int t = j - n_alone;
+            seg_n[0] = n_paired - t;
+            if (t + 1 != seg_n[0]) seg_n[1] = t + 1;   // (middle block of an odd count: alone with half the waves)
+        }
+        int w0 = 0;
+#pragma unroll
+        for (int i = 0; i < kSegs; ++i) {
+            const int g = seg_n[i] ? udiv_magic(seg_n[i] + chain - 1, chain, chain_magic) : 0;
+            seg_mask[i] = ((1u << g) - 1u) << w0;
+            seg_ulo[i] = 0;
+            seg_cnt[i] = seg_n[i];
+            seg_x[i] = 0;
+            w0 += g;
+        }
+    }
 }
 
 // kSegs = 2: the analytic plan (one block or a pair per workgroup); 4: an explicit table (Params::seg_table).
@@ -258,37 +304,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     int seg_n[kSegs];                           // units (= query block index + 1) of each segment's query block; 0 = none
     int seg_ulo[kSegs], seg_cnt[kSegs];          // the segment covers units [ulo, ulo + cnt) of it (the whole block: 0, n)
     unsigned seg_mask[kSegs], seg_x[kSegs];      // waves working on it (bit w = wave w); table word 1 (0 = not a part)
-    if (kSegs > 2) {                              // explicit plan (only this variant is launched with a table)
-#pragma unroll
-        for (int i = 0; i < kSegs; ++i) {
-            const unsigned w0 = tw[2 * i];
-            seg_n[i] = w0 & 255;
-            seg_ulo[i] = (w0 >> 8) & 255;
-            seg_cnt[i] = (w0 >> 16) & 255;
-            seg_mask[i] = w0 >> 24;
-            seg_x[i] = tw[2 * i + 1];
-        }
-    } else {                                      // analytic plan: the longest blocks alone, the others paired n <-> R+1-n
-#pragma unroll
-        for (int i = 0; i < kSegs; ++i) seg_n[i] = 0;
-        if (j < p.n_alone) {
-            seg_n[0] = p.nqb - j;
-        } else {
-            const int t = j - p.n_alone;
-            seg_n[0] = p.n_paired - t;
-            if (t + 1 != seg_n[0]) seg_n[1] = t + 1;   // (middle block of an odd count: alone with half the waves)
-        }
-        int w0 = 0;                               // a block with n units gets ceil(n / c) consecutive waves
-#pragma unroll
-        for (int i = 0; i < kSegs; ++i) {
-            const int g = seg_n[i] ? udiv_magic(seg_n[i] + p.chain - 1, p.chain, p.chain_magic) : 0;
-            seg_mask[i] = ((1u << g) - 1u) << w0;
-            seg_ulo[i] = 0;
-            seg_cnt[i] = seg_n[i];
-            seg_x[i] = 0;
-            w0 += g;
-        }
-    }
+    decode_segments<kSegs>(tw, j, p.nqb, p.n_paired, p.n_alone, p.chain, p.chain_magic, seg_n, seg_ulo, seg_cnt, seg_mask, seg_x);
     // this wave -> (segment, index among the segment's waves); defaults = idle wave: barriers and row work only
     int u_first = 0, u_end = 0, qb = -1, seg_waves = 1, seg = 0, n_seg = 0;
     bool active = false;
@@ -1317,6 +1333,21 @@ size_t plan_workspace_bytes(const Plan &pl, int64_t bh) {
     return pl.parts_per_bh ? kWsCounterBytes + (size_t)bh * pl.parts_per_bh * kPartFloats * 4 : 0;
 }
 
+// grid of a plan: (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8 or
+// too large for gridDim.z; longest first: x = (b,h) in groups of G (a multiple of 8, so that a (b,h) stays on one XCD),
+// y = block, longest first, z = group.  HIP limits: y, z <= 65535, and x * threads < 2^32.
+int plan_grid(const Plan &plan, int64_t bh, dim3 &grid) {
+    const PackPlan &pl = plan.pp;
+    const bool xcd_map = bh % 8 == 0 && bh / 8 <= 65535 && !plan.longest_first;
+    const int64_t lf_groups = plan.longest_first ? (bh + plan.longest_first - 1) / plan.longest_first : 0;
+    if (lf_groups > 65535) return CMHSA_ERR_TOO_LARGE;
+    grid = dim3(plan.longest_first ? (unsigned)plan.longest_first : xcd_map ? 8u : (unsigned)bh, (unsigned)pl.wgs_per_bh,
+                plan.longest_first ? (unsigned)lf_groups : xcd_map ? (unsigned)(bh / 8) : 1u);
+    if (pl.wgs_per_bh > 65535 || (int64_t)grid.x * (pl.waves * 64) >= (1LL << 32) ||
+        (int64_t)grid.x * grid.z * pl.wgs_per_bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    return CMHSA_OK;
+}
+
 // clock probe (cmhsa_probe_shader_clock): 4 independent MFMA chains per wave keep the matrix pipe saturated
 __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long *out4, int iters, float seed) {
     f32x16 a0 = {seed}, a1 = {seed + 1.f}, a2 = {seed + 2.f}, a3 = {seed + 3.f};
@@ -1441,16 +1472,9 @@ int forward(const float *q, const float *k, const float *v, float *o,
     }
     const PackPlan &pl = plan.pp;
     const int waves = pl.waves;
-    // grid = (8, wgs_per_bh, bh/8) pins each (b,h) to one XCD; (bh, wgs_per_bh, 1) when bh is not a multiple of 8
-    // or too large for gridDim.z.  HIP limits: y, z <= 65535, and x * threads < 2^32.
-    const bool xcd_map = bh % 8 == 0 && bh / 8 <= 65535 && !plan.longest_first;
-    // (longest first: x = (b,h), padded to a multiple of 8 so that a (b,h) stays on one XCD; y = block, longest first)
-    const int64_t lf_groups = plan.longest_first ? (bh + plan.longest_first - 1) / plan.longest_first : 0;
-    if (lf_groups > 65535) return CMHSA_ERR_TOO_LARGE;
-    const dim3 grid(plan.longest_first ? (unsigned)plan.longest_first : xcd_map ? 8u : (unsigned)bh, (unsigned)pl.wgs_per_bh,
-                    plan.longest_first ? (unsigned)lf_groups : xcd_map ? (unsigned)(bh / 8) : 1u);
-    if (pl.wgs_per_bh > 65535 || (int64_t)grid.x * (waves * 64) >= (1LL << 32) ||
-        bh * pl.wgs_per_bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    dim3 grid;
+    const int grid_rc = plan_grid(plan, bh, grid);
+    if (grid_rc != CMHSA_OK) return grid_rc;
 
     Params p;
     p.q = q; p.k = k; p.v = v; p.o = o;
@@ -1550,6 +1574,45 @@ int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspac
              pl.family, pl.pp.waves, pl.pp.wgs_per_bh, (long long)bh, cus, pl.pp.chain, pl.simd_cap, pl.splits_per_bh,
              (long long)nqb, plan_workspace_bytes(pl, bh), pl.cycles);
     return CMHSA_OK;
+}
+
+int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, int cus, int *out, int cap) {
+    if (batch <= 0 || seq_len <= 0 || num_heads <= 0) return CMHSA_ERR_BAD_SHAPE;
+    const int64_t nqb = ((int64_t)seq_len + kQBlock - 1) / kQBlock, bh = (int64_t)batch * num_heads;
+    if ((nqb + 16) * kKeyUnit > 0x7fffffffLL || bh > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    if (cus <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        cus = device_cu_count(dev);
+    }
+    const Plan plan = cached_plan(bh, (int)nqb, cus, with_workspace != 0);
+    dim3 grid;
+    const int grid_rc = plan_grid(plan, bh, grid);
+    if (grid_rc != CMHSA_OK) return grid_rc;
+    const int segs = plan.use_table ? kMaxSeg : 2;
+    const int64_t need = 16 + (int64_t)plan.pp.wgs_per_bh * segs * 5;
+    if (need > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
+    if (!out || cap < need) return (int)need;
+    const int header[16] = {plan.pp.waves, segs, plan.pp.wgs_per_bh, (int)grid.x, (int)grid.y, (int)grid.z, plan.parts_per_bh,
+                            plan.splits_per_bh, plan.simd_cap, (int)nqb, plan.use_table ? 1 : 0, plan.longest_first, plan.pp.chain,
+                            plan.pp.n_paired, plan.pp.n_alone, (int)(plan_workspace_bytes(plan, bh) / 256)};
+    memcpy(out, header, sizeof(header));
+    const unsigned chain_magic = 0xffffffffu / (unsigned)plan.pp.chain;
+    for (int j = 0; j < plan.pp.wgs_per_bh; ++j) {
+        int *rec = out + 16 + (int64_t)j * segs * 5;
+        if (plan.use_table) {
+            int n[kMaxSeg], lo[kMaxSeg], cnt[kMaxSeg];
+            unsigned mask[kMaxSeg], x[kMaxSeg];
+            decode_segments<kMaxSeg>(plan.table + j * kTableWords, j, (int)nqb, 0, 0, 1, 0, n, lo, cnt, mask, x);
+            for (int i = 0; i < kMaxSeg; ++i) { rec[5 * i] = n[i]; rec[5 * i + 1] = lo[i]; rec[5 * i + 2] = cnt[i]; rec[5 * i + 3] = (int)mask[i]; rec[5 * i + 4] = (int)x[i]; }
+        } else {
+            int n[2], lo[2], cnt[2];
+            unsigned mask[2], x[2];
+            decode_segments<2>(nullptr, j, (int)nqb, plan.pp.n_paired, plan.pp.n_alone, plan.pp.chain, chain_magic, n, lo, cnt, mask, x);
+            for (int i = 0; i < 2; ++i) { rec[5 * i] = n[i]; rec[5 * i + 1] = lo[i]; rec[5 * i + 2] = cnt[i]; rec[5 * i + 3] = (int)mask[i]; rec[5 * i + 4] = (int)x[i]; }
+        }
+    }
+    return (int)need;
 }
 
 int cmhsa_fp32_fwd_2d(const float *q, const float *k, const float *v, float *o,
