@@ -1,5 +1,5 @@
 """GPU tests of the workspace entry point cmhsa_fp32_fwd_ws: query blocks whose keys are split across workgroups and
-merged through device memory by the workgroup that arrives last (llm-inference_amd/csrc/cmhsa_fwd.hip, "packed" plans).
+merged through device memory by the workgroup that arrives last (llm-inference_amd/csrc/cmhsa_fwd.hip; "packed" plans in cmhsa_plan.h).
 
 What can go wrong there is visibility (a merge that reads another workgroup's partial before it has landed, or a
 stale copy of it) and bookkeeping (arrival counters that do not return to zero), so besides the f64 oracle these tests
