@@ -403,6 +403,18 @@ class Bench:
                             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                          "frac": round(gbs / HBM_PEAK_GBPS, 4), "traffic": None}}
             del gx, gy
+        # fused residual add + LayerNorm (include/gpt2_layernorm.h): HBM-bound, 16 algorithmic bytes per element
+        for name, (rows, cols) in (("add_layernorm_gpt2xl_b64_t512", (64 * 512, 1600)), ("add_layernorm_gpt2_t256", (256, 768))):
+            lx, ld = torch.randn((rows, cols), device=self.dev), torch.randn((rows, cols), device=self.dev)
+            lw, lb = torch.randn(cols, device=self.dev), torch.randn(cols, device=self.dev)
+            ls, ly = torch.empty_like(lx), torch.empty_like(lx)
+            la = (lx.data_ptr(), ld.data_ptr(), lw.data_ptr(), lb.data_ptr(), ls.data_ptr(), ly.data_ptr(), rows, cols, cols, cols, 1e-5, sp)
+            us = self.events_us(lambda: lib.gpt2_add_layernorm_f32_fwd(*la), reps=20, warm=20)
+            gbs = lib.gpt2_add_layernorm_algorithmic_bytes(rows, cols, 1) / us / 1e3
+            others[name] = {"workload": f"fused residual add + LayerNorm fp32, {rows} rows of {cols}", "us_per_launch": round(us, 2),
+                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": round(gbs / HBM_PEAK_GBPS, 4), "traffic": None}}
+            del lx, ld, ls, ly
         # the KV-cache decode step (opt-in): HBM/L2-bound, reads every cached K and V row once
         for name, (db, dh, keys) in (("decode_b64_h25_k512", (64, 25, 512)), ("decode_b1_h12_k512", (1, 12, 512))):
             dd = 64 * dh
@@ -437,9 +449,10 @@ class Bench:
         res = {"prompt": "reference prompt ids (8 tokens)", "max_tokens": 512, "batch": 1, "weights": "seeded random (no checkpoint offline)",
                "note": "seconds = the second, timed run as reference gpt2.py:104-134 (warm-up run first)"}
 
-        def run(model_name, backend, graphs, fused):
+        def run(model_name, backend, graphs, fused, fused_add_ln=False):
             # the small model's weights are drawn on the CPU so that config 1 (CPU) and config 3 (GPU) run the SAME model
-            model = gen.build_model(model_name, backend, self.dev, seed=0, fused_gelu=fused, init_on_device=model_name != "gpt2")
+            model = gen.build_model(model_name, backend, self.dev, seed=0, fused_gelu=fused, fused_add_ln=fused_add_ln,
+                                    init_on_device=model_name != "gpt2")
             g = gen.BucketedGreedyGenerator(model, 1, 512, bucket=64, device=self.dev) if graphs else None
             t = gen.time_greedy_generation(model, prompt, 512, self.dev, g)
             n_new = len(t.tokens[0]) - len(prompt)
@@ -452,7 +465,9 @@ class Bench:
         tok_naive, small["reference_loop_naive_attention"] = run("gpt2", Backend.NAIVE_PYTORCH, False, False)
         tok_hip, small["reference_loop_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, False, False)
         tok_graph, small["hip_graphs_fused_gelu_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, True, True)
-        small["tokens_identical_naive_vs_hip_vs_graphs"] = bool(tok_naive == tok_hip == tok_graph)
+        # + every residual add fused into the LayerNorm behind it (include/gpt2_layernorm.h): 24 launches fewer per token
+        tok_ln, small["hip_graphs_fused_gelu_fused_add_layernorm_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, True, True, True)
+        small["tokens_identical_naive_vs_hip_vs_graphs"] = bool(tok_naive == tok_hip == tok_graph == tok_ln)
         # attention share: the 504 x 12 attention launches of that generation (T = 8..511, H = 12) replayed on their own
         H, d = 12, 768
         qkv = torch.rand((1, 512, 3 * d), device=self.dev)
@@ -482,7 +497,7 @@ class Bench:
             if left() < est:
                 res[name] = "skipped: generation time budget (--gen-budget) spent"
                 continue
-            _, r = run(name, Backend.CUSTOM_CUDA, True, True)
+            _, r = run(name, Backend.CUSTOM_CUDA, True, True)        # (the add + LayerNorm fusion measures within noise on these)
             res[name] = {"hip_graphs_fused_gelu_hip_kernel": r}
         # config 1: naive PyTorch attention on the host CPU (reference loop), all of this host's cores
         if left() >= 45.0:

@@ -1,4 +1,4 @@
-"""ctypes view of the C ABI in include/cmhsa.h and include/gpt2_gelu.h (libcmhsa_hip.so).
+"""ctypes view of the C ABI in include/cmhsa.h, include/gpt2_gelu.h and include/gpt2_layernorm.h (libcmhsa_hip.so).
 
 This is the host-side plumbing only: device memory and streams come from PyTorch-ROCm, the
 arithmetic is entirely in the hand-written gfx950 kernels.  There is NO fallback: if the library
@@ -45,6 +45,8 @@ EXPORTED_SYMBOLS = (
     "cmhsa_probe_shader_clock",
     "gpt2_gelu_tanh_f32_fwd",        # include/gpt2_gelu.h
     "gpt2_gelu_algorithmic_bytes",
+    "gpt2_add_layernorm_f32_fwd",    # include/gpt2_layernorm.h
+    "gpt2_add_layernorm_algorithmic_bytes",
 )
 
 CMHSA_OK = 0
@@ -112,6 +114,10 @@ def load_library() -> ctypes.CDLL:
     lib.gpt2_gelu_tanh_f32_fwd.argtypes = [vp, vp, i64, vp]
     lib.gpt2_gelu_algorithmic_bytes.restype = ctypes.c_double
     lib.gpt2_gelu_algorithmic_bytes.argtypes = [i64]
+    lib.gpt2_add_layernorm_f32_fwd.restype = i32
+    lib.gpt2_add_layernorm_f32_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i64, i64, ctypes.c_float, vp]
+    lib.gpt2_add_layernorm_algorithmic_bytes.restype = ctypes.c_double
+    lib.gpt2_add_layernorm_algorithmic_bytes.argtypes = [i64, i32, i32]
     _lib = lib
     return lib
 

@@ -31,6 +31,7 @@
 
 #include "cmhsa.h"
 #include "gpt2_gelu.h"
+#include "gpt2_layernorm.h"
 
 namespace causal_multihead_self_attention {
 
@@ -175,11 +176,43 @@ at::Tensor gelu_tanh(at::Tensor x) {
     return y;
 }
 
+// Fused residual add + LayerNorm (include/gpt2_layernorm.h; the reference has nn.LayerNorm and a torch add,
+// transformer_block.py:26-39, no extension op to mirror): x (..., d) and optionally delta of the same shape, fp32 device
+// tensors whose last dimension is contiguous and whose leading dimensions collapse to one row stride (else copied).
+// Returns (x + delta, LayerNorm(x + delta)); without delta the first is x itself.
+std::tuple<at::Tensor, at::Tensor> add_layer_norm(at::Tensor x, const c10::optional<at::Tensor> &delta, at::Tensor weight,
+                                                  at::Tensor bias, double eps) {
+    TORCH_CHECK(x.is_cuda() && weight.is_cuda() && bias.is_cuda(), "x, weight and bias must be CUDA tensors");
+    TORCH_CHECK(x.dtype() == at::kFloat && weight.dtype() == at::kFloat && bias.dtype() == at::kFloat, "tensors must be float32");
+    TORCH_CHECK(x.dim() >= 1, "x must have at least one dimension");
+    const int64_t d = x.size(-1);
+    TORCH_CHECK(weight.numel() == d && bias.numel() == d, "weight and bias must have x.size(-1) elements");
+    TORCH_CHECK(weight.device() == x.device() && bias.device() == x.device(), "all tensors must be on the same device");
+    const at::Tensor xc = x.contiguous(), wc = weight.contiguous(), bc = bias.contiguous();
+    at::Tensor dc;
+    if (delta.has_value()) {
+        TORCH_CHECK(delta->is_cuda() && delta->dtype() == at::kFloat && delta->sizes() == x.sizes() && delta->device() == x.device(),
+                    "delta must be a float32 CUDA tensor of x's shape on x's device");
+        dc = delta->contiguous();
+    }
+    at::Tensor y = at::empty_like(xc);
+    at::Tensor sum = delta.has_value() ? at::empty_like(xc) : xc;
+    if (xc.numel() == 0) return {sum, y};
+    const c10::hip::HIPGuard guard(x.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(x.device().index()).stream();
+    const int rc = gpt2_add_layernorm_f32_fwd(xc.data_ptr<float>(), delta.has_value() ? dc.data_ptr<float>() : nullptr, wc.data_ptr<float>(),
+                                              bc.data_ptr<float>(), delta.has_value() ? sum.data_ptr<float>() : nullptr, y.data_ptr<float>(),
+                                              xc.numel() / d, (int)d, d, d, (float)eps, stream);
+    TORCH_CHECK(rc == CMHSA_OK, "gpt2_add_layernorm_f32_fwd failed (", rc, "): ", cmhsa_status_string(rc));
+    return {sum, y};
+}
+
 TORCH_LIBRARY(causal_multihead_self_attention, m) {
     m.def("causal_multihead_self_attention_torch(Tensor Q, Tensor K, Tensor V, int num_heads) -> Tensor");
     m.def("causal_multihead_self_attention_packed_qkv(Tensor QKV, int num_heads) -> Tensor");
     m.def("causal_multihead_self_attention_decode(Tensor qkv_new, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor pos, int num_heads) -> Tensor");
     m.def("gelu_tanh(Tensor x) -> Tensor");
+    m.def("add_layer_norm(Tensor x, Tensor? delta, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
@@ -187,6 +220,7 @@ TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
     m.impl("causal_multihead_self_attention_packed_qkv", &causal_multihead_self_attention_packed_qkv);
     m.impl("causal_multihead_self_attention_decode", &causal_multihead_self_attention_decode);
     m.impl("gelu_tanh", &gelu_tanh);
+    m.impl("add_layer_norm", &add_layer_norm);
 }
 
 }  // namespace causal_multihead_self_attention

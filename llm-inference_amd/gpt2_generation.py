@@ -50,6 +50,20 @@ COMMON = dict(vocab_size=50257, context_length=1024, drop_rate=0.1, qkv_bias=Tru
 
 
 
+def _add_layer_norm_op():
+    import causal_multihead_self_attention  # noqa: F401  (in-tree extension: registers the ops on import)
+
+    return torch.ops.causal_multihead_self_attention.add_layer_norm
+
+
+def fused_add_layer_norm(x: torch.Tensor, delta, ln: nn.LayerNorm):
+    """(x + delta, ln(x + delta)) in ONE launch of gpt2_add_layernorm_f32_fwd (include/gpt2_layernorm.h); delta None:
+    (x, ln(x)).  Device tensors only -- there is no CPU fallback."""
+    if not x.is_cuda:
+        raise RuntimeError("fused add + LayerNorm runs the HIP kernel only: the input must be a device tensor")
+    return _add_layer_norm_op()(x, delta, ln.weight, ln.bias, ln.eps)
+
+
 class Block(nn.Module):
     """Pre-LN block: x + attn(LN(x)); x + mlp(LN(x)) (transformer_block.py:26-39); dropouts are identity in eval()."""
 
@@ -69,13 +83,24 @@ class Block(nn.Module):
         x = x + self.attention(self.first_layer_norm(x))
         return x + self.mlp_out(self.gelu(self.mlp_in(self.second_layer_norm(x))))
 
+    def forward_split(self, x, delta):
+        """The same block with every residual add fused into the LayerNorm that follows it.  In: the residual stream x
+        and the output `delta` of the previous sublayer, not yet added (None at the first block).  Out: the same pair
+        after this block: (x + delta + attention(...), mlp(...))."""
+        x, h = fused_add_layer_norm(x, delta, self.first_layer_norm)
+        x, h = fused_add_layer_norm(x, self.attention(h), self.second_layer_norm)
+        return x, self.mlp_out(self.gelu(self.mlp_in(h)))
+
 
 class GPT2Model(nn.Module):
     def __init__(self, cfg: dict, backend: ScaledDotProductAttentionBackend, last_position_only: bool = False,
-                 fused_gelu: bool = False):
+                 fused_gelu: bool = False, fused_add_ln: bool = False):
         super().__init__()
         self.cfg = cfg
         self.last_position_only = last_position_only      # opt-in (SURVEY 8(f) row 3); default = reference behaviour
+        self.fused_add_ln = fused_add_ln                  # opt-in: residual add + next LayerNorm as one HIP launch
+        if fused_add_ln:
+            _add_layer_norm_op()                          # fail at construction, loudly, if the extension is missing
         self.token_embeddings = nn.Embedding(cfg["vocab_size"], cfg["emb_dim"])
         self.positional_embeddings = nn.Embedding(cfg["context_length"], cfg["emb_dim"])
         self.blocks = nn.ModuleList(Block(cfg, backend, fused_gelu) for _ in range(cfg["n_layers"]))
@@ -84,14 +109,35 @@ class GPT2Model(nn.Module):
 
     def hidden_states(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens (B, T) -> residual stream (B, T, emb_dim) after the last block, before the final LayerNorm."""
+        if self.fused_add_ln:
+            x, delta = self.hidden_states_split(tokens)
+            return x + delta
         n = tokens.shape[1]
         x = self.token_embeddings(tokens) + self.positional_embeddings(torch.arange(n, device=tokens.device))
         for blk in self.blocks:
             x = blk(x)
         return x
 
+    def hidden_states_split(self, tokens: torch.Tensor):
+        """fused_add_ln form: (x, delta) with the residual stream = x + delta -- the last MLP output is left for the final
+        LayerNorm's launch to add (final_norm())."""
+        n = tokens.shape[1]
+        x = self.token_embeddings(tokens) + self.positional_embeddings(torch.arange(n, device=tokens.device))
+        delta = None
+        for blk in self.blocks:
+            x, delta = blk.forward_split(x, delta)
+        return x, delta
+
+    def final_norm(self, x: torch.Tensor, delta) -> torch.Tensor:
+        return fused_add_layer_norm(x, delta, self.layer_norm)[1]
+
     def forward(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens (B, T) -> logits (B, T, vocab) (reference gpt2.py:41-45), or (B, 1, vocab) with last_position_only."""
+        if self.fused_add_ln:
+            x, delta = self.hidden_states_split(tokens)
+            if self.last_position_only:                   # LayerNorm is per position: normalise the one row that is used
+                x, delta = x[:, -1:, :], delta[:, -1:, :]
+            return self.output_layer(self.final_norm(x, delta))
         x = self.layer_norm(self.hidden_states(tokens))
         if self.last_position_only:
             x = x[:, -1:, :]
@@ -126,7 +172,7 @@ class GPT2Model(nn.Module):
 
 def build_model(name: str, backend: ScaledDotProductAttentionBackend, device, weights: str | None = None, seed: int = 0,
                 last_position_only: bool = False, overrides: dict | None = None, fused_gelu: bool = False,
-                init_on_device: bool = False) -> GPT2Model:
+                init_on_device: bool = False, fused_add_ln: bool = False) -> GPT2Model:
     """init_on_device: draw the random weights on `device` directly (seconds instead of tens of seconds for GPT2-XL;
     the values then come from the device's generator, not the CPU's -- fine for timing, and every rank that seeds alike
     gets the same weights).  The default draws them on the CPU, so that CPU and GPU models of one seed are equal."""
@@ -134,9 +180,9 @@ def build_model(name: str, backend: ScaledDotProductAttentionBackend, device, we
     torch.manual_seed(seed)                       # seeded random weights unless a local checkpoint is given
     if init_on_device and torch.device(device).type != "cpu":
         with torch.device(device):
-            model = GPT2Model(cfg, backend, last_position_only, fused_gelu)
+            model = GPT2Model(cfg, backend, last_position_only, fused_gelu, fused_add_ln)
     else:
-        model = GPT2Model(cfg, backend, last_position_only, fused_gelu)
+        model = GPT2Model(cfg, backend, last_position_only, fused_gelu, fused_add_ln)
     if weights:
         model.load_hf_safetensors(weights)
     return model.eval().to(device)
@@ -215,8 +261,12 @@ class BucketedGreedyGenerator:
     @torch.no_grad()
     def _step(self, L: int) -> None:
         m = self.model
-        x = m.hidden_states(self.tokens[:, :L])
-        h = m.layer_norm(x.index_select(1, self.pos))                 # (B, 1, emb_dim): LayerNorm is per position
+        if getattr(m, "fused_add_ln", False):
+            x, delta = m.hidden_states_split(self.tokens[:, :L])
+            h = m.final_norm(x.index_select(1, self.pos), delta.index_select(1, self.pos))
+        else:
+            x = m.hidden_states(self.tokens[:, :L])
+            h = m.layer_norm(x.index_select(1, self.pos))             # (B, 1, emb_dim): LayerNorm is per position
         nxt = torch.argmax(m.output_layer(h)[:, 0, :], dim=-1)        # first max wins, as in the reference
         nxt = torch.where(self.done, torch.full_like(nxt, self.eos), nxt)
         self.done.logical_or_(nxt == self.eos)
@@ -467,6 +517,7 @@ def main() -> None:
     ap.add_argument("--kv-cache", action="store_true", help="opt-in KV-cache decoding (one position per token, one HIP graph); not the reference's algorithm")
     ap.add_argument("--progress", action="store_true", help="with --graphs: a line on stderr at every EOS check (32 tokens)")
     ap.add_argument("--fused-gelu", action="store_true", help="GELU as one HIP launch (include/gpt2_gelu.h) instead of eight torch ops")
+    ap.add_argument("--fused-add-ln", action="store_true", help="every residual add + the LayerNorm after it as one HIP launch (include/gpt2_layernorm.h)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -488,7 +539,7 @@ def main() -> None:
                                 **({"device_id": device} if device.type == "cuda" else {}))
 
     model = build_model(args.model, backend, device, weights=args.weights, last_position_only=args.last_position_lm_head,
-                        fused_gelu=args.fused_gelu)
+                        fused_gelu=args.fused_gelu, fused_add_ln=args.fused_add_ln)
     mine = shard_prompts(args.batch, rank, world)
     prompts = [list(REFERENCE_PROMPT_IDS) for _ in mine]
     if world > 1:
@@ -516,7 +567,7 @@ def main() -> None:
         tokens = timing.tokens
     if rank == 0:
         print(json.dumps({
-            "model": args.model, "backend": args.backend, "loop": "kv cache, one hip graph" if args.kv_cache else f"hip graphs, bucket {args.bucket}" if args.graphs else "eager (reference loop)", "gelu": "fused HIP kernel" if args.fused_gelu else "reference expression (8 torch ops)", "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
+            "model": args.model, "backend": args.backend, "loop": "kv cache, one hip graph" if args.kv_cache else f"hip graphs, bucket {args.bucket}" if args.graphs else "eager (reference loop)", "gelu": "fused HIP kernel" if args.fused_gelu else "reference expression (8 torch ops)", "add_layer_norm": "fused HIP kernel" if args.fused_add_ln else "torch add + nn.LayerNorm", "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
             "cpu_threads": torch.get_num_threads() if device.type == "cpu" else None,
             "weights": args.weights or "random (torch.manual_seed(0))", "prompts": args.batch, "max_tokens": args.max_tokens,
             "warmup_seconds": round(timing.first_run_seconds, 4), "seconds": round(seconds, 4),

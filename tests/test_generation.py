@@ -232,6 +232,19 @@ def test_hip_graph_generation_identical_to_reference_loop_on_gpu(gpu_device):
     assert gen.greedy_generate(fused, prompt, 128) == [ref[0][:128]]
     gf = gen.BucketedGreedyGenerator(fused, 1, 512, bucket=64, device=gpu_device)
     assert gf.generate(prompt) == ref
+    # nor does fusing every residual add into the LayerNorm behind it (include/gpt2_layernorm.h): eager model forward
+    # (logits of all positions within fp32 rounding of the unfused model), reference loop, HIP-graph loop
+    both = gen.build_model("gpt2", Backend.CUSTOM_CUDA, gpu_device, seed=0, fused_gelu=True, fused_add_ln=True)
+    toks = torch.tensor([ref[0][:200]], device=gpu_device)
+    with torch.no_grad():
+        a, b = fused(toks), both(toks)
+    assert (a - b).abs().max().item() <= 1e-4 * float(a.abs().max())
+    assert torch.equal(a.argmax(-1), b.argmax(-1))
+    assert gen.greedy_generate(both, prompt, 128) == [ref[0][:128]]
+    gb = gen.BucketedGreedyGenerator(both, 1, 512, bucket=64, device=gpu_device)
+    assert gb.generate(prompt) == ref
+    gb3 = gen.BucketedGreedyGenerator(both, 3, 160, bucket=32, device=gpu_device)
+    assert gb3.generate([prompt] * 3) == [ref[0][:160]] * 3
 
 
 @pytest.mark.gpu
@@ -272,3 +285,6 @@ def test_gpt2_xl_width_batch8_tokens_identical_to_naive_on_gpu(gpu_device):
     assert all(row == got[0] for row in got)
     g = gen.BucketedGreedyGenerator(hip, 8, 64, bucket=32, device=gpu_device)
     assert g.generate(prompts) == ref
+    fused = gen.build_model("gpt2-xl", Backend.CUSTOM_CUDA, gpu_device, overrides=xl2, seed=7, fused_gelu=True, fused_add_ln=True)
+    gf = gen.BucketedGreedyGenerator(fused, 8, 64, bucket=32, device=gpu_device)
+    assert gf.generate(prompts) == ref
