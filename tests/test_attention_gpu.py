@@ -462,3 +462,31 @@ def test_random_shapes_fuzz(gpu_device):
         worst = max(worst, err)
         assert err <= TOL, (B, H, T, err)
     assert worst <= 1e-5, worst          # randn inputs: observed ~1e-6
+
+
+def test_random_larger_grids_fuzz(gpu_device):
+    """Thirty seeded random shapes with 1 500 to 40 000 (batch, head, query block) triples -- the range where the planner
+    moves between the analytic plan, wave pairs and longest-first one-wave workgroups -- ragged lengths, B*H mostly not
+    a multiple of 8; whole output against the oracle's formula in float64, and the plan family recorded so that the test
+    fails if the sweep stops reaching the one-wave families."""
+    rng = np.random.default_rng(77)
+    families = set()
+    done = 0
+    while done < 30:
+        B = int(rng.integers(1, 65)); H = int(rng.integers(1, 27)); T = int(rng.integers(40, 1300))
+        nqb = (T + 31) // 32
+        if not (1500 <= B * H * nqb <= 40000) or B * H * T * T > 6e8:
+            continue
+        done += 1
+        families.add(cmhsa.plan_description(B, T, H).split(":")[0])
+        d = 64 * H
+        g = torch.Generator(device="cpu").manual_seed(int(rng.integers(1 << 30)))
+        qkv = torch.randn((B, T, 3 * d), generator=g).to(gpu_device)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        out = torch.full((B, T, d), float("nan"), device=gpu_device)
+        cmhsa.attention_fwd(q, k, v, H, out=out)
+        want = oracle.naive_attention_torch(q.double(), k.double(), v.double(), H)
+        err = (out.double() - want).abs().max().item()
+        assert err <= 1e-5, (B, H, T, err, cmhsa.plan_description(B, T, H))
+        del qkv, out, want
+    assert PAIRS in families and LONGEST_FIRST in families, families
