@@ -8,27 +8,34 @@ src = os.path.join(root, "gpurun_out", f"prof_{rnd}")
 dst = os.path.join(root, "profiles")
 
 
-def first(pattern):
+def newest(pattern):
+    """gpurun MERGES each session's files into gpurun_out/ (rocprofv3 names them by process id), so files of earlier
+    sessions stay behind: only the newest match belongs to the session being collected."""
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 for name in ("bench_config2", "bench_config5_shard", "bench_config5_n1"):
     shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, f"{rnd}_{name}.json"))
 for tag in ("bench_py", "config2", "config5_shard"):
-    f = first(f"trace_{tag}/**/*kernel_stats.csv")
+    f = newest(f"trace_{tag}/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv" if tag != "bench_py" else f"{rnd}_bench_py_config2_kernel_stats.csv"))
 for tag in ("config2", "config5_shard"):
     tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
-    for f in glob.glob(os.path.join(src, f"pmc_{tag}", "pass*", "**", "*counter_collection.csv"), recursive=True):
+    for pass_dir in sorted(glob.glob(os.path.join(src, f"pmc_{tag}", "pass*"))):
+        if not os.path.isdir(pass_dir):
+            continue
+        f = newest(os.path.relpath(os.path.join(pass_dir, "**", "*counter_collection.csv"), src))
+        if not f:
+            continue
         for row in csv.DictReader(open(f)):
             if "cmhsa_fwd" not in row["Kernel_Name"]:
                 continue
             tot[row["Counter_Name"]] += float(row["Counter_Value"])
             cnt[row["Counter_Name"]] += 1
     mean = {k: tot[k] / cnt[k] for k in sorted(tot)}
-    f = first(f"trace_{tag}/**/*kernel_stats.csv")
+    f = newest(f"trace_{tag}/**/*kernel_stats.csv")
     if f:
         for row in csv.DictReader(open(f)):
             if "cmhsa_fwd" in row["Name"]:
