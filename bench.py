@@ -449,10 +449,10 @@ class Bench:
         res = {"prompt": "reference prompt ids (8 tokens)", "max_tokens": 512, "batch": 1, "weights": "seeded random (no checkpoint offline)",
                "note": "seconds = the second, timed run as reference gpt2.py:104-134 (warm-up run first)"}
 
-        def run(model_name, backend, graphs, fused, fused_add_ln=False):
+        def run(model_name, backend, graphs, fused, fused_all=False):
             # the small model's weights are drawn on the CPU so that config 1 (CPU) and config 3 (GPU) run the SAME model
-            model = gen.build_model(model_name, backend, self.dev, seed=0, fused_gelu=fused, fused_add_ln=fused_add_ln,
-                                    init_on_device=model_name != "gpt2")
+            model = gen.build_model(model_name, backend, self.dev, seed=0, fused_gelu=fused, fused_add_ln=fused_all,
+                                    fused_step_ops=fused_all, init_on_device=model_name != "gpt2")
             g = gen.BucketedGreedyGenerator(model, 1, 512, bucket=64, device=self.dev) if graphs else None
             t = gen.time_greedy_generation(model, prompt, 512, self.dev, g)
             n_new = len(t.tokens[0]) - len(prompt)
@@ -465,8 +465,9 @@ class Bench:
         tok_naive, small["reference_loop_naive_attention"] = run("gpt2", Backend.NAIVE_PYTORCH, False, False)
         tok_hip, small["reference_loop_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, False, False)
         tok_graph, small["hip_graphs_fused_gelu_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, True, True)
-        # + every residual add fused into the LayerNorm behind it (include/gpt2_layernorm.h): 24 launches fewer per token
-        tok_ln, small["hip_graphs_fused_gelu_fused_add_layernorm_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, True, True, True)
+        # + every residual add fused into the LayerNorm behind it (include/gpt2_layernorm.h) and the loop's bookkeeping --
+        # embedding sum, next-token step -- as one launch each (include/gpt2_step.h): 33 launches fewer per token
+        tok_ln, small["hip_graphs_all_fusions_hip_kernel"] = run("gpt2", Backend.CUSTOM_CUDA, True, True, True)
         small["tokens_identical_naive_vs_hip_vs_graphs"] = bool(tok_naive == tok_hip == tok_graph == tok_ln)
         # attention share: the 504 x 12 attention launches of that generation (T = 8..511, H = 12) replayed on their own
         H, d = 12, 768
@@ -497,8 +498,8 @@ class Bench:
             if left() < est:
                 res[name] = "skipped: generation time budget (--gen-budget) spent"
                 continue
-            _, r = run(name, Backend.CUSTOM_CUDA, True, True)        # (the add + LayerNorm fusion measures within noise on these)
-            res[name] = {"hip_graphs_fused_gelu_hip_kernel": r}
+            _, r = run(name, Backend.CUSTOM_CUDA, True, True, True)
+            res[name] = {"hip_graphs_all_fusions_hip_kernel": r}
         # config 1: naive PyTorch attention on the host CPU (reference loop), all of this host's cores
         if left() >= 45.0:
             cores = host_cores()
@@ -592,7 +593,8 @@ class Bench:
             n_prompts, overrides = 8, dict(n_layers=2)
         mine = gen.shard_prompts(n_prompts, self.rank, self.world)
         prompts = [list(gen.REFERENCE_PROMPT_IDS) for _ in mine]
-        model = gen.build_model(model_name, Backend.CUSTOM_CUDA, self.dev, seed=0, fused_gelu=True, init_on_device=True, overrides=overrides)
+        model = gen.build_model(model_name, Backend.CUSTOM_CUDA, self.dev, seed=0, fused_gelu=True, fused_add_ln=True, fused_step_ops=True,
+                                init_on_device=True, overrides=overrides)
         g = gen.BucketedGreedyGenerator(model, len(prompts), max_tokens, bucket=64, device=self.dev)
         g.generate(prompts)                                      # captures the graphs (warm-up)
         self.fence()
@@ -610,7 +612,7 @@ class Bench:
         del g, model
         torch.cuda.empty_cache()
         return {"workload": f"{model_name} fp32, {n_prompts} prompts over {self.world} GPU(s) ({len(prompts)} on rank 0), "
-                            f"{max_tokens} total tokens each (bounded sample of the 512-token config), HIP graphs + fused GELU",
+                            f"{max_tokens} total tokens each (bounded sample of the 512-token config), HIP graphs + fused GELU, add + LayerNorm and step kernels",
                 "seconds": round(seconds, 3), "tokens_generated_all_gpus": int(generated),
                 "tokens_per_second_all_gpus": round(generated / seconds, 1), "rows_identical_on_rank0": bool(rows_equal)}
 

@@ -47,6 +47,8 @@ EXPORTED_SYMBOLS = (
     "gpt2_gelu_algorithmic_bytes",
     "gpt2_add_layernorm_f32_fwd",    # include/gpt2_layernorm.h
     "gpt2_add_layernorm_algorithmic_bytes",
+    "gpt2_embed_f32_fwd",            # include/gpt2_step.h
+    "gpt2_greedy_step",
 )
 
 CMHSA_OK = 0
@@ -118,6 +120,10 @@ def load_library() -> ctypes.CDLL:
     lib.gpt2_add_layernorm_f32_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i64, i64, ctypes.c_float, vp]
     lib.gpt2_add_layernorm_algorithmic_bytes.restype = ctypes.c_double
     lib.gpt2_add_layernorm_algorithmic_bytes.argtypes = [i64, i32, i32]
+    lib.gpt2_embed_f32_fwd.restype = i32
+    lib.gpt2_embed_f32_fwd.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.gpt2_greedy_step.restype = i32
+    lib.gpt2_greedy_step.argtypes = [vp, i64, vp, vp, i64, vp, i32, i32, i32, i64, vp]
     _lib = lib
     return lib
 

@@ -70,6 +70,69 @@ __global__ __launch_bounds__(kRowsPerWg * 64) void add_layernorm_kernel(const fl
     }
 }
 
+// Few rows (the B = 1 generation loop: <= 512 rows): ONE WORKGROUP per row, so that a launch is rows x 4 waves instead of
+// rows waves (GPT2-XL, 256 rows of 1600: one wave per row measured slower than torch's add + LayerNorm pair).  The two
+// statistics cross the four waves through LDS.
+__device__ __forceinline__ float wg_sum(float v, float *slots, int wave) {
+    v = wave_sum(v);
+    __syncthreads();                               // (the slots of the previous reduction have been read)
+    if ((threadIdx.x & 63) == 0) slots[wave] = v;
+    __syncthreads();
+    return (slots[0] + slots[1]) + (slots[2] + slots[3]);
+}
+
+template <int kVec, bool kDelta>
+__global__ __launch_bounds__(256) void add_layernorm_row_per_wg_kernel(const float *x, const float *delta, const float *weight,
+                                                                       const float *bias, float *sum_out, float *norm_out,
+                                                                       int64_t rows, int cols, int64_t x_rs, int64_t d_rs, float eps) {
+    __shared__ float slots[4];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int nvec = cols >> 2;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x + row * x_rs);
+    const f32x4 *d4 = kDelta ? reinterpret_cast<const f32x4 *>(delta + row * d_rs) : nullptr;
+    f32x4 v[kVec];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kVec; ++i) {
+        const int idx = tid + 256 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < nvec) {
+            v[i] = x4[idx];
+            if (kDelta) v[i] += d4[idx];
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wg_sum(sum, slots, wave) / (float)cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kVec; ++i) {
+        if (tid + 256 * i < nvec) {
+            const f32x4 c = v[i] - mean;
+            sq += (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
+        }
+    }
+    const float rstd = rsqrtf(wg_sum(sq, slots, wave) / (float)cols + eps);
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(weight), *b4 = reinterpret_cast<const f32x4 *>(bias);
+    f32x4 *s4 = (kDelta && sum_out) ? reinterpret_cast<f32x4 *>(sum_out + row * (int64_t)cols) : nullptr;
+    f32x4 *y4 = reinterpret_cast<f32x4 *>(norm_out + row * (int64_t)cols);
+#pragma unroll
+    for (int i = 0; i < kVec; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < nvec) {
+            if (s4) s4[idx] = v[i];
+            y4[idx] = w4[idx] * (rstd * (v[i] - mean)) + b4[idx];
+        }
+    }
+}
+
+template <int kVec>
+hipError_t launch_row_per_wg(bool with_delta, void **args, int64_t rows, hipStream_t s) {
+    const void *k = with_delta ? reinterpret_cast<const void *>(add_layernorm_row_per_wg_kernel<kVec, true>)
+                               : reinterpret_cast<const void *>(add_layernorm_row_per_wg_kernel<kVec, false>);
+    return hipLaunchKernel(k, dim3((unsigned)rows), dim3(256), args, 0, s);
+}
+
 template <int kVec>
 hipError_t launch(bool with_delta, void **args, int64_t rows, hipStream_t s) {
     const void *k = with_delta ? reinterpret_cast<const void *>(add_layernorm_kernel<kVec, true>)
@@ -98,6 +161,12 @@ int gpt2_add_layernorm_f32_fwd(const float *x, const float *delta, const float *
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool d = delta != nullptr;
     const int nvec_per_lane = (cols / 4 + 63) / 64;                // float4 per lane
+    if (cols >= 512) {                                             // wide rows: one workgroup per row
+        const int per_thread = (cols / 4 + 255) / 256;
+        const hipError_t e1 = per_thread <= 1 ? launch_row_per_wg<1>(d, args, rows, s) : per_thread <= 2 ? launch_row_per_wg<2>(d, args, rows, s)
+                                                                                                         : launch_row_per_wg<4>(d, args, rows, s);
+        return e1 == hipSuccess ? CMHSA_OK : (int)e1;
+    }
     const hipError_t e = nvec_per_lane <= 4 ? launch<4>(d, args, rows, s) : nvec_per_lane <= 8 ? launch<8>(d, args, rows, s)
                                                                                               : launch<16>(d, args, rows, s);
     return e == hipSuccess ? CMHSA_OK : (int)e;     // this launch's own status

@@ -32,6 +32,7 @@
 #include "cmhsa.h"
 #include "gpt2_gelu.h"
 #include "gpt2_layernorm.h"
+#include "gpt2_step.h"
 
 namespace causal_multihead_self_attention {
 
@@ -207,12 +208,52 @@ std::tuple<at::Tensor, at::Tensor> add_layer_norm(at::Tensor x, const c10::optio
     return {sum, y};
 }
 
+// The generation loop's input side (include/gpt2_step.h; reference gpt2.py:43-44): tokens (B, L) int64 (a view of the
+// static token buffer: any row stride), wte (vocab, d), wpe (context, d) -> (B, L, d) = wte[tokens] + wpe[arange(L)].
+at::Tensor embed_tokens(at::Tensor tokens, at::Tensor wte, at::Tensor wpe) {
+    TORCH_CHECK(tokens.is_cuda() && wte.is_cuda() && wpe.is_cuda(), "tokens, wte and wpe must be CUDA tensors");
+    TORCH_CHECK(tokens.dtype() == at::kLong && tokens.dim() == 2 && (tokens.size(1) <= 1 || tokens.stride(1) == 1), "tokens must be (B, L) int64 with contiguous rows");
+    TORCH_CHECK(wte.dtype() == at::kFloat && wpe.dtype() == at::kFloat && wte.dim() == 2 && wpe.dim() == 2 && wte.is_contiguous() && wpe.is_contiguous(),
+                "wte and wpe must be contiguous float32 matrices");
+    TORCH_CHECK(wte.size(1) == wpe.size(1) && tokens.size(1) <= wpe.size(0), "embedding widths differ or the sequence is longer than the context");
+    TORCH_CHECK(wte.device() == tokens.device() && wpe.device() == tokens.device(), "all tensors must be on the same device");
+    const int64_t B = tokens.size(0), L = tokens.size(1), d = wte.size(1);
+    at::Tensor x = at::empty({B, L, d}, wte.options());
+    if (x.numel() == 0) return x;
+    const c10::hip::HIPGuard guard(tokens.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(tokens.device().index()).stream();
+    const int rc = gpt2_embed_f32_fwd(tokens.data_ptr<int64_t>(), tokens.stride(0), wte.data_ptr<float>(), wpe.data_ptr<float>(), x.data_ptr<float>(),
+                                      (int)B, (int)L, (int)d, (int)wte.size(0), stream);
+    TORCH_CHECK(rc == CMHSA_OK, "gpt2_embed_f32_fwd failed (", rc, "): ", cmhsa_status_string(rc));
+    return x;
+}
+
+// The sampler's side (include/gpt2_step.h; reference sampler.py:14-19): logits (B, vocab), done (B) bool, tokens (B, cap)
+// int64, pos (1) int64.  Writes tokens[:, pos + 1] and done in place; pos itself is left for the caller to increment.
+void greedy_step(at::Tensor logits, at::Tensor done, at::Tensor tokens, at::Tensor pos, int64_t eos) {
+    TORCH_CHECK(logits.is_cuda() && done.is_cuda() && tokens.is_cuda() && pos.is_cuda(), "all tensors must be CUDA tensors");
+    TORCH_CHECK(logits.dtype() == at::kFloat && logits.dim() == 2 && logits.stride(1) == 1, "logits must be (B, vocab) float32 with contiguous rows");
+    TORCH_CHECK(done.dtype() == at::kBool && done.dim() == 1 && done.is_contiguous() && done.size(0) == logits.size(0), "done must be (B) bool");
+    TORCH_CHECK(tokens.dtype() == at::kLong && tokens.dim() == 2 && tokens.stride(1) == 1 && tokens.size(0) == logits.size(0), "tokens must be (B, cap) int64");
+    TORCH_CHECK(pos.dtype() == at::kLong && pos.numel() == 1, "pos must hold one int64");
+    TORCH_CHECK(done.device() == logits.device() && tokens.device() == logits.device() && pos.device() == logits.device(), "all tensors must be on the same device");
+    if (logits.size(0) == 0) return;
+    const c10::hip::HIPGuard guard(logits.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(logits.device().index()).stream();
+    const int rc = gpt2_greedy_step(logits.data_ptr<float>(), logits.stride(0), reinterpret_cast<unsigned char *>(done.data_ptr<bool>()),
+                                    tokens.data_ptr<int64_t>(), tokens.stride(0), pos.data_ptr<int64_t>(), (int)logits.size(0), (int)logits.size(1),
+                                    (int)tokens.size(1), eos, stream);
+    TORCH_CHECK(rc == CMHSA_OK, "gpt2_greedy_step failed (", rc, "): ", cmhsa_status_string(rc));
+}
+
 TORCH_LIBRARY(causal_multihead_self_attention, m) {
     m.def("causal_multihead_self_attention_torch(Tensor Q, Tensor K, Tensor V, int num_heads) -> Tensor");
     m.def("causal_multihead_self_attention_packed_qkv(Tensor QKV, int num_heads) -> Tensor");
     m.def("causal_multihead_self_attention_decode(Tensor qkv_new, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor pos, int num_heads) -> Tensor");
     m.def("gelu_tanh(Tensor x) -> Tensor");
     m.def("add_layer_norm(Tensor x, Tensor? delta, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor)");
+    m.def("embed_tokens(Tensor tokens, Tensor wte, Tensor wpe) -> Tensor");
+    m.def("greedy_step(Tensor logits, Tensor(a!) done, Tensor(b!) tokens, Tensor pos, int eos) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
@@ -221,6 +262,8 @@ TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
     m.impl("causal_multihead_self_attention_decode", &causal_multihead_self_attention_decode);
     m.impl("gelu_tanh", &gelu_tanh);
     m.impl("add_layer_norm", &add_layer_norm);
+    m.impl("embed_tokens", &embed_tokens);
+    m.impl("greedy_step", &greedy_step);
 }
 
 }  // namespace causal_multihead_self_attention

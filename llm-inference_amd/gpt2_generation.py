@@ -94,9 +94,14 @@ class Block(nn.Module):
 
 class GPT2Model(nn.Module):
     def __init__(self, cfg: dict, backend: ScaledDotProductAttentionBackend, last_position_only: bool = False,
-                 fused_gelu: bool = False, fused_add_ln: bool = False):
+                 fused_gelu: bool = False, fused_add_ln: bool = False, fused_step_ops: bool = False):
         super().__init__()
         self.cfg = cfg
+        # opt-in: token + positional embedding as one HIP launch (include/gpt2_step.h); the graph loop then also picks
+        # the next token with gpt2_greedy_step instead of seven torch launches
+        self.fused_step_ops = fused_step_ops
+        if fused_step_ops:
+            _add_layer_norm_op()                          # (loads the extension: fail at construction if it is missing)
         self.last_position_only = last_position_only      # opt-in; default = reference behaviour
         self.fused_add_ln = fused_add_ln                  # opt-in: residual add + next LayerNorm as one HIP launch
         if fused_add_ln:
@@ -107,13 +112,22 @@ class GPT2Model(nn.Module):
         self.layer_norm = nn.LayerNorm(cfg["emb_dim"])
         self.output_layer = nn.Linear(cfg["emb_dim"], cfg["vocab_size"], bias=False)
 
+    def embed(self, tokens: torch.Tensor) -> torch.Tensor:
+        """wte[tokens] + wpe[arange(T)] (reference gpt2.py:43-44)."""
+        if self.fused_step_ops:
+            if not tokens.is_cuda:
+                raise RuntimeError("fused_step_ops runs HIP kernels only: the tokens must be a device tensor")
+            return torch.ops.causal_multihead_self_attention.embed_tokens(tokens, self.token_embeddings.weight,
+                                                                          self.positional_embeddings.weight)
+        n = tokens.shape[1]
+        return self.token_embeddings(tokens) + self.positional_embeddings(torch.arange(n, device=tokens.device))
+
     def hidden_states(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens (B, T) -> residual stream (B, T, emb_dim) after the last block, before the final LayerNorm."""
         if self.fused_add_ln:
             x, delta = self.hidden_states_split(tokens)
             return x + delta
-        n = tokens.shape[1]
-        x = self.token_embeddings(tokens) + self.positional_embeddings(torch.arange(n, device=tokens.device))
+        x = self.embed(tokens)
         for blk in self.blocks:
             x = blk(x)
         return x
@@ -121,8 +135,7 @@ class GPT2Model(nn.Module):
     def hidden_states_split(self, tokens: torch.Tensor):
         """fused_add_ln form: (x, delta) with the residual stream = x + delta -- the last MLP output is left for the final
         LayerNorm's launch to add (final_norm())."""
-        n = tokens.shape[1]
-        x = self.token_embeddings(tokens) + self.positional_embeddings(torch.arange(n, device=tokens.device))
+        x = self.embed(tokens)
         delta = None
         for blk in self.blocks:
             x, delta = blk.forward_split(x, delta)
@@ -172,7 +185,7 @@ class GPT2Model(nn.Module):
 
 def build_model(name: str, backend: ScaledDotProductAttentionBackend, device, weights: str | None = None, seed: int = 0,
                 last_position_only: bool = False, overrides: dict | None = None, fused_gelu: bool = False,
-                init_on_device: bool = False, fused_add_ln: bool = False) -> GPT2Model:
+                init_on_device: bool = False, fused_add_ln: bool = False, fused_step_ops: bool = False) -> GPT2Model:
     """init_on_device: draw the random weights on `device` directly (seconds instead of tens of seconds for GPT2-XL;
     the values then come from the device's generator, not the CPU's -- fine for timing, and every rank that seeds alike
     gets the same weights).  The default draws them on the CPU, so that CPU and GPU models of one seed are equal."""
@@ -180,9 +193,9 @@ def build_model(name: str, backend: ScaledDotProductAttentionBackend, device, we
     torch.manual_seed(seed)                       # seeded random weights unless a local checkpoint is given
     if init_on_device and torch.device(device).type != "cpu":
         with torch.device(device):
-            model = GPT2Model(cfg, backend, last_position_only, fused_gelu, fused_add_ln)
+            model = GPT2Model(cfg, backend, last_position_only, fused_gelu, fused_add_ln, fused_step_ops)
     else:
-        model = GPT2Model(cfg, backend, last_position_only, fused_gelu, fused_add_ln)
+        model = GPT2Model(cfg, backend, last_position_only, fused_gelu, fused_add_ln, fused_step_ops)
     if weights:
         model.load_hf_safetensors(weights)
     return model.eval().to(device)
@@ -267,6 +280,10 @@ class BucketedGreedyGenerator:
         else:
             x = m.hidden_states(self.tokens[:, :L])
             h = m.layer_norm(x.index_select(1, self.pos))             # (B, 1, emb_dim): LayerNorm is per position
+        if getattr(m, "fused_step_ops", False):                       # arg-max, EOS rule and token write: one launch
+            torch.ops.causal_multihead_self_attention.greedy_step(m.output_layer(h)[:, 0, :], self.done, self.tokens, self.pos, self.eos)
+            self.pos.add_(1)
+            return
         nxt = torch.argmax(m.output_layer(h)[:, 0, :], dim=-1)        # first max wins, as in the reference
         nxt = torch.where(self.done, torch.full_like(nxt, self.eos), nxt)
         self.done.logical_or_(nxt == self.eos)
@@ -517,6 +534,7 @@ def main() -> None:
     ap.add_argument("--kv-cache", action="store_true", help="opt-in KV-cache decoding (one position per token, one HIP graph); not the reference's algorithm")
     ap.add_argument("--progress", action="store_true", help="with --graphs: a line on stderr at every EOS check (32 tokens)")
     ap.add_argument("--fused-gelu", action="store_true", help="GELU as one HIP launch (include/gpt2_gelu.h) instead of eight torch ops")
+    ap.add_argument("--fused-step-ops", action="store_true", help="embedding sum and next-token pick (arg-max, EOS, token write) as one HIP launch each (include/gpt2_step.h)")
     ap.add_argument("--fused-add-ln", action="store_true", help="every residual add + the LayerNorm after it as one HIP launch (include/gpt2_layernorm.h)")
     args = ap.parse_args()
 
@@ -539,7 +557,7 @@ def main() -> None:
                                 **({"device_id": device} if device.type == "cuda" else {}))
 
     model = build_model(args.model, backend, device, weights=args.weights, last_position_only=args.last_position_lm_head,
-                        fused_gelu=args.fused_gelu, fused_add_ln=args.fused_add_ln)
+                        fused_gelu=args.fused_gelu, fused_add_ln=args.fused_add_ln, fused_step_ops=args.fused_step_ops)
     mine = shard_prompts(args.batch, rank, world)
     prompts = [list(REFERENCE_PROMPT_IDS) for _ in mine]
     if world > 1:
@@ -567,7 +585,7 @@ def main() -> None:
         tokens = timing.tokens
     if rank == 0:
         print(json.dumps({
-            "model": args.model, "backend": args.backend, "loop": "kv cache, one hip graph" if args.kv_cache else f"hip graphs, bucket {args.bucket}" if args.graphs else "eager (reference loop)", "gelu": "fused HIP kernel" if args.fused_gelu else "reference expression (8 torch ops)", "add_layer_norm": "fused HIP kernel" if args.fused_add_ln else "torch add + nn.LayerNorm", "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
+            "model": args.model, "backend": args.backend, "loop": "kv cache, one hip graph" if args.kv_cache else f"hip graphs, bucket {args.bucket}" if args.graphs else "eager (reference loop)", "gelu": "fused HIP kernel" if args.fused_gelu else "reference expression (8 torch ops)", "add_layer_norm": "fused HIP kernel" if args.fused_add_ln else "torch add + nn.LayerNorm", "step_ops": "fused HIP kernels" if args.fused_step_ops else "torch ops", "device": str(device), "n_gpus": world if device.type == "cuda" else 0,
             "cpu_threads": torch.get_num_threads() if device.type == "cpu" else None,
             "weights": args.weights or "random (torch.manual_seed(0))", "prompts": args.batch, "max_tokens": args.max_tokens,
             "warmup_seconds": round(timing.first_run_seconds, 4), "seconds": round(seconds, 4),

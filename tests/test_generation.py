@@ -245,6 +245,16 @@ def test_hip_graph_generation_identical_to_reference_loop_on_gpu(gpu_device):
     assert gb.generate(prompt) == ref
     gb3 = gen.BucketedGreedyGenerator(both, 3, 160, bucket=32, device=gpu_device)
     assert gb3.generate([prompt] * 3) == [ref[0][:160]] * 3
+    # and with the loop's bookkeeping as two HIP launches (include/gpt2_step.h): embedding sum, next-token step
+    every = gen.build_model("gpt2", Backend.CUSTOM_CUDA, gpu_device, seed=0, fused_gelu=True, fused_add_ln=True, fused_step_ops=True)
+    with torch.no_grad():
+        assert torch.equal(every(toks), b)                              # the embedding sum is exact
+    ge = gen.BucketedGreedyGenerator(every, 1, 512, bucket=64, device=gpu_device)
+    assert ge.generate(prompt) == ref and ge.generate(prompt) == ref
+    ge3 = gen.BucketedGreedyGenerator(every, 3, 160, bucket=32, device=gpu_device)
+    assert ge3.generate([prompt] * 3) == [ref[0][:160]] * 3
+    ee = gen.BucketedGreedyGenerator(every, 2, 40, bucket=16, device=gpu_device, use_graphs=False)
+    assert ee.generate([prompt] * 2) == [ref[0][:40]] * 2
 
 
 @pytest.mark.gpu
