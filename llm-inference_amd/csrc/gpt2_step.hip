@@ -42,7 +42,17 @@ __global__ __launch_bounds__(kPickThreads) void greedy_step_kernel(const float *
     const float *row = logits + b * lrs;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < vocab; i += kPickThreads) better(bv, bi, row[i], i);
+    // eight independent loads in flight per thread (a row of 50 257 logits is 49 per thread: latency, not bandwidth)
+    for (int base = tid; base < vocab; base += 8 * kPickThreads) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + k * kPickThreads;
+            v[k] = i < vocab ? row[i] : -INFINITY;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) better(bv, bi, v[k], min(base + k * kPickThreads, vocab - 1));
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) better(bv, bi, __shfl_xor(bv, m, 64), __shfl_xor(bi, m, 64));
     if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }

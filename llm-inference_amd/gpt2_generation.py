@@ -276,7 +276,12 @@ class BucketedGreedyGenerator:
         m = self.model
         if getattr(m, "fused_add_ln", False):
             x, delta = m.hidden_states_split(self.tokens[:, :L])
-            h = m.final_norm(x.index_select(1, self.pos), delta.index_select(1, self.pos))
+            if x.shape[0] * x.shape[1] <= 1024:
+                # LayerNorm is per position: normalising these few rows costs one launch, as one row would, and leaves ONE
+                # tensor to pick the row from
+                h = m.final_norm(x, delta).index_select(1, self.pos)
+            else:
+                h = m.final_norm(x.index_select(1, self.pos), delta.index_select(1, self.pos))
         else:
             x = m.hidden_states(self.tokens[:, :L])
             h = m.layer_norm(x.index_select(1, self.pos))             # (B, 1, emb_dim): LayerNorm is per position
