@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kPickThreads) void greedy_step_kernel(const float *
             v[k] = i < vocab ? row[i] : -INFINITY;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) better(bv, bi, v[k], min(base + k * kPickThreads, vocab - 1));
+        for (int k = 0; k < 8; ++k)
+            if (base + k * kPickThreads < vocab) better(bv, bi, v[k], base + k * kPickThreads);
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) better(bv, bi, __shfl_xor(bv, m, 64), __shfl_xor(bi, m, 64));

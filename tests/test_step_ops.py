@@ -73,6 +73,13 @@ def test_greedy_step_equals_the_torch_chain(gpu_device):
         assert torch.equal(tokens, want_tokens) and torch.equal(done, want_done)
         assert int(pos) == 10 + trial                                 # pos is the caller's to increment
         assert tokens[0, int(pos) + 1].item() == 777 and tokens[4, int(pos) + 1].item() == 5
+    # a row of NaNs picks index 0 (documented), a row of -inf as well (torch.argmax's answer)
+    weird = torch.full((2, vocab), float("nan"), device=gpu_device)
+    weird[1] = float("-inf")
+    d2 = torch.zeros(2, dtype=torch.bool, device=gpu_device)
+    t2 = torch.full((2, cap), 7, dtype=torch.long, device=gpu_device)
+    op(weird, d2, t2, torch.tensor([3], device=gpu_device), eos)
+    assert t2[:, 4].tolist() == [0, 0] and not d2.any()
     # writing past the buffer is refused silently (nothing written)
     before = tokens.clone()
     op(logits, done, tokens, torch.tensor([cap - 1], device=gpu_device), eos)
