@@ -89,8 +89,26 @@ def self_launch(args) -> int:
                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # a rank that dies (no such device, a failed check) would leave the others waiting in a rendezvous or a barrier for
+    # torch's time-out: as soon as one exits non-zero, the rest are ended (these exact child processes, nothing else)
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        if all(c is not None for c in codes):
+            break
+        time.sleep(0.2)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=20))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
     if out0:
         sys.stdout.write(out0)
         sys.stdout.flush()
@@ -152,6 +170,9 @@ class Bench:
         # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (never for reported numbers):
         # CMHSA_BENCH_BACKEND=gloo lets several ranks share a card (RCCL refuses two ranks on one device)
         self.backend = os.environ.get("CMHSA_BENCH_BACKEND", "nccl")
+        if self.backend == "nccl" and local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {local_rank} has no GPU: --gpus {args.gpus} on a host with {torch.cuda.device_count()} "
+                             "(one rank per GPU; CMHSA_BENCH_BACKEND=gloo rehearses the code path on fewer cards)")
         dev_index = local_rank % torch.cuda.device_count() if self.backend != "nccl" else local_rank
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)

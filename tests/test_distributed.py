@@ -143,6 +143,23 @@ def test_bench_self_launches_two_ranks_in_rehearsal_mode():
     assert c4["tokens_generated_all_gpus"] > 0 and c4["rows_identical_on_rank0"]
 
 
+@pytest.mark.gpu
+def test_bench_self_launch_fails_fast_when_a_rank_has_no_gpu():
+    """`--gpus 2` with RCCL on a box with ONE GPU: rank 1 has no device and exits; the launcher must end rank 0 (which would
+    otherwise sit in the rendezvous until torch's time-out) and report, within seconds."""
+    import subprocess
+    import time
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CMHSA_BENCH_BACKEND")}
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=150)
+    assert r.returncode != 0 and time.perf_counter() - t0 < 120
+    assert "has no GPU" in r.stderr and "child ranks exited" in r.stderr
+
+
 def test_bench_self_launch_relays_child_failure_on_a_box_without_gpu():
     """No WORLD_SIZE in the environment and --gpus 2: the parent starts two ranks and must itself stay off the GPU.
     On a CPU-only box the ranks exit with "needs a GPU"; the parent reports it and exits non-zero.  (On the GPU box the
