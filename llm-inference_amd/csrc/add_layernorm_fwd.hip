@@ -81,7 +81,7 @@ __device__ __forceinline__ float wg_sum(float v, float *slots, int wave) {
     return (slots[0] + slots[1]) + (slots[2] + slots[3]);
 }
 
-template <int kVec, bool kDelta>
+template <int kVec, bool kDelta, bool kStream>
 __global__ __launch_bounds__(256) void add_layernorm_row_per_wg_kernel(const float *x, const float *delta, const float *weight,
                                                                        const float *bias, float *sum_out, float *norm_out,
                                                                        int64_t rows, int cols, int64_t x_rs, int64_t d_rs, float eps) {
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void add_layernorm_row_per_wg_kernel(const flo
         const int idx = tid + 256 * i;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (idx < nvec) {
-            v[i] = x4[idx];
-            if (kDelta) v[i] += d4[idx];
+            v[i] = kStream ? __builtin_nontemporal_load(x4 + idx) : x4[idx];
+            if (kDelta) v[i] += kStream ? __builtin_nontemporal_load(d4 + idx) : d4[idx];
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
@@ -120,16 +120,24 @@ __global__ __launch_bounds__(256) void add_layernorm_row_per_wg_kernel(const flo
     for (int i = 0; i < kVec; ++i) {
         const int idx = tid + 256 * i;
         if (idx < nvec) {
-            if (s4) s4[idx] = v[i];
-            y4[idx] = w4[idx] * (rstd * (v[i] - mean)) + b4[idx];
+            const f32x4 out = w4[idx] * (rstd * (v[i] - mean)) + b4[idx];
+            if (kStream) {                         // arrays beyond the Infinity Cache: every byte is touched once
+                if (s4) __builtin_nontemporal_store(v[i], s4 + idx);
+                __builtin_nontemporal_store(out, y4 + idx);
+            } else {
+                if (s4) s4[idx] = v[i];
+                y4[idx] = out;
+            }
         }
     }
 }
 
 template <int kVec>
-hipError_t launch_row_per_wg(bool with_delta, void **args, int64_t rows, hipStream_t s) {
-    const void *k = with_delta ? reinterpret_cast<const void *>(add_layernorm_row_per_wg_kernel<kVec, true>)
-                               : reinterpret_cast<const void *>(add_layernorm_row_per_wg_kernel<kVec, false>);
+hipError_t launch_row_per_wg(bool with_delta, bool streaming, void **args, int64_t rows, hipStream_t s) {
+    const void *k = with_delta ? (streaming ? reinterpret_cast<const void *>(add_layernorm_row_per_wg_kernel<kVec, true, true>)
+                                            : reinterpret_cast<const void *>(add_layernorm_row_per_wg_kernel<kVec, true, false>))
+                               : (streaming ? reinterpret_cast<const void *>(add_layernorm_row_per_wg_kernel<kVec, false, true>)
+                                            : reinterpret_cast<const void *>(add_layernorm_row_per_wg_kernel<kVec, false, false>));
     return hipLaunchKernel(k, dim3((unsigned)rows), dim3(256), args, 0, s);
 }
 
@@ -163,8 +171,9 @@ int gpt2_add_layernorm_f32_fwd(const float *x, const float *delta, const float *
     const int nvec_per_lane = (cols / 4 + 63) / 64;                // float4 per lane
     if (cols >= 512) {                                             // wide rows: one workgroup per row
         const int per_thread = (cols / 4 + 255) / 256;
-        const hipError_t e1 = per_thread <= 1 ? launch_row_per_wg<1>(d, args, rows, s) : per_thread <= 2 ? launch_row_per_wg<2>(d, args, rows, s)
-                                                                                                         : launch_row_per_wg<4>(d, args, rows, s);
+        const bool st = (double)rows * cols * 4.0 * (d ? 4.0 : 2.0) > 128.0 * 1048576.0;      // larger than half the Infinity Cache
+        const hipError_t e1 = per_thread <= 1 ? launch_row_per_wg<1>(d, st, args, rows, s) : per_thread <= 2 ? launch_row_per_wg<2>(d, st, args, rows, s)
+                                                                                                             : launch_row_per_wg<4>(d, st, args, rows, s);
         return e1 == hipSuccess ? CMHSA_OK : (int)e1;
     }
     const hipError_t e = nvec_per_lane <= 4 ? launch<4>(d, args, rows, s) : nvec_per_lane <= 8 ? launch<8>(d, args, rows, s)
