@@ -412,8 +412,38 @@ class KVCacheGreedyGenerator:
             x = x + blk.mlp_out(blk.gelu(blk.mlp_in(blk.second_layer_norm(x))))
 
     @torch.no_grad()
+    def _step_fused(self) -> None:
+        """The same step with the model's opt-in fusions: every residual add inside the LayerNorm behind it
+        (fused_add_ln) and the next-token pick as one launch (fused_step_ops)."""
+        m = self.model
+        tok = self.tokens.index_select(1, self.pos64)
+        x = m.token_embeddings(tok) + m.positional_embeddings(self.pos64)
+        delta = None
+        for i, blk in enumerate(m.blocks):
+            a = blk.attention
+            x, h = fused_add_layer_norm(x, delta, blk.first_layer_norm)
+            qkv = a.qkv_layer(h)
+            ctx = self.decode_fn(qkv[:, 0, :], self.k_cache[i], self.v_cache[i], self.pos32, a.num_heads)
+            x, h = fused_add_layer_norm(x, a.out_proj_layer(ctx).unsqueeze(1), blk.second_layer_norm)
+            delta = blk.mlp_out(blk.gelu(blk.mlp_in(h)))
+        logits = m.output_layer(m.final_norm(x, delta))[:, 0, :]
+        if getattr(m, "fused_step_ops", False):
+            torch.ops.causal_multihead_self_attention.greedy_step(logits, self.done, self.tokens, self.pos64, self.eos)
+            self.pos64.add_(1)
+            self.pos32.add_(1)
+            return
+        nxt = torch.argmax(logits, dim=-1)
+        nxt = torch.where(self.done, torch.full_like(nxt, self.eos), nxt)
+        self.done.logical_or_(nxt == self.eos)
+        self.pos64.add_(1)
+        self.pos32.add_(1)
+        self.tokens.index_copy_(1, self.pos64, nxt.unsqueeze(1))
+
+    @torch.no_grad()
     def _step(self) -> None:
         m = self.model
+        if getattr(m, "fused_add_ln", False):
+            return self._step_fused()
         tok = self.tokens.index_select(1, self.pos64)                                  # (B, 1)
         x = m.token_embeddings(tok) + m.positional_embeddings(self.pos64)              # (B, 1, d)
         for i, blk in enumerate(m.blocks):

@@ -277,6 +277,12 @@ def test_kv_cache_generation_on_gpu(gpu_device):
     assert e.generate(prompt) == [ref[0][:96]]
     g3 = gen.KVCacheGreedyGenerator(hip, 3, 128, device=gpu_device)
     assert g3.generate([prompt] * 3) == [ref[0][:128]] * 3
+    # with the add + LayerNorm and next-token kernels in the step as well
+    every = gen.build_model("gpt2", Backend.CUSTOM_CUDA, gpu_device, seed=0, fused_gelu=True, fused_add_ln=True, fused_step_ops=True)
+    gk = gen.KVCacheGreedyGenerator(every, 1, 512, device=gpu_device)
+    assert gk.generate(prompt) == ref and gk.generate(prompt) == ref
+    gk3 = gen.KVCacheGreedyGenerator(every, 3, 128, device=gpu_device)
+    assert gk3.generate([prompt] * 3) == [ref[0][:128]] * 3
 
 
 @pytest.mark.gpu
