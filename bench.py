@@ -513,6 +513,17 @@ class Bench:
         small["attention_kernel_seconds_6048_launches"] = round(att_s, 4)
         small["attention_share_of_reference_loop_hip"] = round(att_s / small["reference_loop_hip_kernel"]["seconds"], 4)
         small["attention_share_of_hip_graph_loop"] = round(att_s / small["hip_graphs_fused_gelu_hip_kernel"]["seconds"], 4)
+        # opt-in KV-cache mode (NOT the reference's algorithm, which keeps no cache): one position per token
+        if left() >= 15.0:
+            model = gen.build_model("gpt2", Backend.CUSTOM_CUDA, self.dev, seed=0, fused_gelu=True, fused_add_ln=True, fused_step_ops=True)
+            kv = gen.KVCacheGreedyGenerator(model, 1, 512, device=self.dev)
+            t = gen.time_greedy_generation(model, prompt, 512, self.dev, kv)
+            n_new = len(t.tokens[0]) - len(prompt)
+            small["kv_cache_opt_in_all_fusions"] = {"seconds": round(t.second_run_seconds, 4), "tokens_generated": n_new,
+                                                    "tokens_per_second": round(n_new / t.second_run_seconds, 1),
+                                                    "tokens_identical_to_reference_loop": bool(t.tokens[0] == tok_naive)}
+            del kv, model
+            torch.cuda.empty_cache()
         res["gpt2"] = small
         del qkv, out, launches
         for name, est in (("gpt2-medium", 8.0), ("gpt2-large", 14.0), ("gpt2-xl", 22.0)):
