@@ -18,9 +18,9 @@ constexpr int kKeyUnit = 32;            // keys per unit (one MFMA M-tile)
 //   8 -> one workgroup per CU (two of its waves per SIMD; 224 VGPRs allow no more): shortest chain per query block
 //   4 -> two workgroups per CU: prologue/merge of one overlaps the main loop of the other
 constexpr int kUnitFloats = kKeyUnit * kHeadDim;          // 2048 floats = 8 KiB
-constexpr int kMaxSeg = 4;                                // query blocks ("segments") one workgroup can hold (template kSegs: 2 or 4)
-constexpr int kMaxTableWgs = 64;                          // workgroups per (b,h) an explicit segment table can describe
-constexpr int kTableWords = 2 * kMaxSeg;                  // table words per workgroup: two per segment (see Params::seg_table)
+constexpr int kMaxSeg = 8;                                // query blocks ("segments") one workgroup can hold (template kSegs: 2, 4 or 8)
+constexpr int kMaxTableWgs = 64;                          // workgroups per (b,h) a 4-segment table can describe (an 8-segment table: 32)
+constexpr int kTableSize = kMaxTableWgs * 2 * 4;              // words of Params::seg_table: two per segment, 64 x 4 or 32 x 8 segments
 constexpr int kMaxParts = 4;                              // parts (on different workgroups) a query block's keys may be split into
 // One part's un-normalised result in the workspace: O image [8 pairs][64 lanes] float4 (the merge's native layout)
 // followed by (m, l) of the 32 queries.  33 whole 256-B lines.
@@ -45,8 +45,9 @@ struct Params {
     int chain;                          // c: max units any wave processes (>= ceil(nqb / kWaves))
     int n_paired;                       // R: query blocks 1..R units long are paired n <-> R+1-n
     int n_alone;                        // nqb - R: the longest query blocks get a workgroup each
-    // explicit plan (use_table != 0; choose_plan()): workgroup j of every (b,h) holds up to four segments, two table
-    // words each (seg_table[j * 8 + 2 i], [.. + 1]; a segment with n = 0 is absent, present ones come first):
+    // explicit plan (use_table != 0; choose_plan()): workgroup j of every (b,h) holds up to S = four or eight segments
+    // (the kernel's kSegs), two table words each (seg_table[j * 2S + 2 i], [.. + 1]; a segment with n = 0 is absent, present
+    // ones come first):
     //   word 0: n (units of the query block = block index + 1) | first unit << 8 | unit count << 16 | wave mask << 24
     //           -- the waves of the mask take the units [first, first + count) round-robin; count < n = the block's keys
     //           are split across workgroups and this segment is one PART of it
@@ -58,7 +59,7 @@ struct Params {
     float *ws_parts;
     unsigned *ws_counters;
     int parts_per_bh, splits_per_bh;
-    unsigned seg_table[kMaxTableWgs * kTableWords];
+    unsigned seg_table[kTableSize];
 };
 
 // Packing plan.  A query block with n units gets g(n) = ceil(n / c) waves, so that no wave runs more than c units
@@ -92,7 +93,7 @@ __host__ __device__ __forceinline__ int udiv_magic(int n, int d, unsigned magic)
 
 // Workgroup j of a (b,h) -> its segments.  ONE definition for the kernel and for the host (cmhsa_plan_dump(), which the
 // CPU tests use to check that every plan covers every unit of every query block exactly once).
-//   kSegs > 2: explicit plan, `tw` = the workgroup's eight table words (Params::seg_table);
+//   kSegs > 2: explicit plan, `tw` = the workgroup's 2 * kSegs table words (Params::seg_table);
 //   else the analytic plan: the n_alone longest blocks alone, the others paired n <-> n_paired+1-n (the middle block of an
 //   odd count alone); a block with n units gets ceil(n / chain) consecutive waves.
 template <int kSegs>

@@ -52,12 +52,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // LDS: [kWaves][8 KiB] each wave's K unit (later its merge image) | [kSegs][8 KiB] pre-scaled query blocks |
-//      [kWaves][32 x (m, l)] softmax statistics for the merge | [4] "this workgroup arrived last" flags (split plans)
+//      [kWaves][32 x (m, l)] softmax statistics for the merge | [8] "this workgroup arrived last" flags (split plans)
 constexpr int lds_floats_q(int waves) { return waves * kUnitFloats; }
 constexpr int lds_floats_ml(int waves, int segs) { return (waves + segs) * kUnitFloats; }
 constexpr int lds_floats_flags(int waves, int segs) { return lds_floats_ml(waves, segs) + waves * 64; }
 // (one-wave workgroups keep nothing but their K unit in LDS: no shared query blocks, no merge)
-constexpr int lds_bytes(int waves, int segs) { return waves == 1 ? kUnitFloats * 4 : (lds_floats_flags(waves, segs) + 4) * 4; }   // <= 98 KiB (8 waves), 65 KiB (4), 8 KiB (1)
+constexpr int lds_bytes(int waves, int segs) { return waves == 1 ? kUnitFloats * 4 : (lds_floats_flags(waves, segs) + 8) * 4; }   // <= 130 KiB (8 waves, 8 segments), 98 KiB (8, 4), 65 KiB (4), 8 KiB (1)
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
 constexpr int kSc1 = 16;                                   // buffer load/store aux bits on gfx950: 16 = sc1 (agent-coherent: stores write through, loads bypass the CU's L1)
 constexpr float kRescaleSum = 1.8446744e19f;              // 2^64: a row sum of P above it triggers the rescale path
@@ -163,10 +163,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     // the blocks that use them -- five dependent round trips to a cold kernarg segment (~2 k cycles, measured)
     // before the first global load could be issued.
     // (the table variant's eight words of this workgroup ride in the same batch: their address needs blockIdx.y only)
-    unsigned tw[kTableWords];
+    unsigned tw[2 * kSegs];
     if constexpr (kSegs > 2) {
 #pragma unroll
-        for (int i = 0; i < kTableWords; ++i) tw[i] = p.seg_table[blockIdx.y * kTableWords + i];
+        for (int i = 0; i < 2 * kSegs; ++i) tw[i] = p.seg_table[blockIdx.y * (2 * kSegs) + i];
+        if constexpr (kSegs > 4)
+            asm volatile("" ::"s"(tw[8]), "s"(tw[9]), "s"(tw[10]), "s"(tw[11]), "s"(tw[12]), "s"(tw[13]), "s"(tw[14]), "s"(tw[15]));
         asm volatile("" ::"s"(tw[0]), "s"(tw[1]), "s"(tw[2]), "s"(tw[3]), "s"(tw[4]), "s"(tw[5]), "s"(tw[6]), "s"(tw[7]),
                      "s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs), "s"(p.v_rs), "s"(p.o_rs));
     } else
@@ -605,7 +607,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 unsigned *flags = reinterpret_cast<unsigned *>(lds + lds_floats_flags(kWaves, kSegs));
                 if (threadIdx.x < kSegs) {
                     const int t = threadIdx.x;
-                    const unsigned x = t == 0 ? seg_x[0] : t == 1 ? seg_x[1] : t == 2 ? seg_x[2] : seg_x[3];
+                    unsigned x = 0;
+#pragma unroll
+                    for (int i = 0; i < kSegs; ++i) x = t == i ? seg_x[i] : x;
                     unsigned last = 0;
                     if (x) {
                         unsigned *cnt = p.ws_counters + (int64_t)bh * p.splits_per_bh + (x >> 16);
@@ -670,14 +674,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 #endif
 }
 
-std::atomic<int> g_attr_set[6][64];  // per variant and device: dynamic-LDS limit raised once, not per call
+std::atomic<int> g_attr_set[8][64];  // per variant and device: dynamic-LDS limit raised once, not per call
 
 template <int kWaves, int kSegs, bool kAcquire>
 hipError_t launch(const Params &p, dim3 grid, void *stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kWaves == 1 ? 5 : kAcquire ? 4 : (kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
+    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kWaves == 1 ? 5 : kSegs == 8 ? 6 + kAcquire : kAcquire ? 4 : (kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
     if (!flag || !flag->load(std::memory_order_acquire)) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs, kAcquire>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kWaves, kSegs));
@@ -864,12 +868,13 @@ int forward(const float *q, const float *k, const float *v, float *o,
     p.ws_parts = split ? reinterpret_cast<float *>(static_cast<char *>(workspace) + kWsCounterBytes) : nullptr;
     p.parts_per_bh = plan.parts_per_bh;
     p.splits_per_bh = plan.splits_per_bh;
-    if (plan.use_table) memcpy(p.seg_table, plan.table, sizeof(unsigned) * (size_t)plan.n_wgs * kTableWords);
+    if (plan.use_table) memcpy(p.seg_table, plan.table, sizeof(unsigned) * (size_t)plan.n_wgs * 2 * plan.segs);
 
     hipError_t e;
     if (waves == 1) e = launch<1, 2, false>(p, grid, stream);
     else if (!p.use_table) e = waves == 8 ? launch<8, 2, false>(p, grid, stream) : launch<4, 2, false>(p, grid, stream);
     else if (waves == 4) e = launch<4, 4, false>(p, grid, stream);
+    else if (plan.segs == 8) e = split && acquire ? launch<8, 8, true>(p, grid, stream) : launch<8, 8, false>(p, grid, stream);
     else e = split && acquire ? launch<8, 4, true>(p, grid, stream) : launch<8, 4, false>(p, grid, stream);
     return e == hipSuccess ? CMHSA_OK : (int)e;     // launch-configuration errors only; no synchronisation (CMHSA.cu:450)
 }
@@ -959,7 +964,7 @@ int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, i
     dim3 grid;
     const int grid_rc = plan_grid(plan, bh, grid);
     if (grid_rc != CMHSA_OK) return grid_rc;
-    const int segs = plan.use_table ? kMaxSeg : 2;
+    const int segs = plan.use_table ? plan.segs : 2;
     const int64_t need = 16 + (int64_t)plan.pp.wgs_per_bh * segs * 5;
     if (need > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;
     if (!out || cap < need) return (int)need;
@@ -970,17 +975,22 @@ int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, i
     const unsigned chain_magic = 0xffffffffu / (unsigned)plan.pp.chain;
     for (int j = 0; j < plan.pp.wgs_per_bh; ++j) {
         int *rec = out + 16 + (int64_t)j * segs * 5;
-        if (plan.use_table) {
-            int n[kMaxSeg], lo[kMaxSeg], cnt[kMaxSeg];
-            unsigned mask[kMaxSeg], x[kMaxSeg];
-            decode_segments<kMaxSeg>(plan.table + j * kTableWords, j, (int)nqb, 0, 0, 1, 0, n, lo, cnt, mask, x);
-            for (int i = 0; i < kMaxSeg; ++i) { rec[5 * i] = n[i]; rec[5 * i + 1] = lo[i]; rec[5 * i + 2] = cnt[i]; rec[5 * i + 3] = (int)mask[i]; rec[5 * i + 4] = (int)x[i]; }
+        int n[kMaxSeg], lo[kMaxSeg], cnt[kMaxSeg];
+        unsigned mask[kMaxSeg], x[kMaxSeg];
+        if (plan.use_table && segs == 8) {
+            decode_segments<8>(plan.table + j * 16, j, (int)nqb, 0, 0, 1, 0, n, lo, cnt, mask, x);
+        } else if (plan.use_table) {
+            int n4[4], lo4[4], cnt4[4];
+            unsigned mask4[4], x4[4];
+            decode_segments<4>(plan.table + j * 8, j, (int)nqb, 0, 0, 1, 0, n4, lo4, cnt4, mask4, x4);
+            for (int i = 0; i < 4; ++i) { n[i] = n4[i]; lo[i] = lo4[i]; cnt[i] = cnt4[i]; mask[i] = mask4[i]; x[i] = x4[i]; }
         } else {
-            int n[2], lo[2], cnt[2];
-            unsigned mask[2], x[2];
-            decode_segments<2>(nullptr, j, (int)nqb, plan.pp.n_paired, plan.pp.n_alone, plan.pp.chain, chain_magic, n, lo, cnt, mask, x);
-            for (int i = 0; i < 2; ++i) { rec[5 * i] = n[i]; rec[5 * i + 1] = lo[i]; rec[5 * i + 2] = cnt[i]; rec[5 * i + 3] = (int)mask[i]; rec[5 * i + 4] = (int)x[i]; }
+            int n2[2], lo2[2], cnt2[2];
+            unsigned mask2[2], x2[2];
+            decode_segments<2>(nullptr, j, (int)nqb, plan.pp.n_paired, plan.pp.n_alone, plan.pp.chain, chain_magic, n2, lo2, cnt2, mask2, x2);
+            for (int i = 0; i < 2; ++i) { n[i] = n2[i]; lo[i] = lo2[i]; cnt[i] = cnt2[i]; mask[i] = mask2[i]; x[i] = x2[i]; }
         }
+        for (int i = 0; i < segs; ++i) { rec[5 * i] = n[i]; rec[5 * i + 1] = lo[i]; rec[5 * i + 2] = cnt[i]; rec[5 * i + 3] = (int)mask[i]; rec[5 * i + 4] = (int)x[i]; }
     }
     return (int)need;
 }

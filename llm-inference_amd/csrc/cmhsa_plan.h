@@ -49,7 +49,8 @@ struct Plan {
     int longest_first = 0;                       // G > 0: one-wave workgroups, one block each; (b,h)s in groups of G (a multiple of 8), within a group longest blocks first
     double cycles = 0.0;
     const char *family = "analytic";
-    unsigned table[kMaxTableWgs * kTableWords];  // table plans: Params::seg_table
+    int segs = 4;                                // table plans: segments per workgroup record (4 or 8)
+    unsigned table[kTableSize];                  // table plans: Params::seg_table
 };
 
 inline unsigned seg_word0(int n, int lo, int cnt, unsigned mask) { return (unsigned)n | ((unsigned)lo << 8) | ((unsigned)cnt << 16) | (mask << 24); }
@@ -68,13 +69,15 @@ int busiest_simd(const int *n, int k, int c, int waves) {
     return m;
 }
 
-void price(Plan &pl, const int (*wg_blocks)[kMaxSeg], int n_wgs, int64_t bh, int cus) {
+constexpr int kChainSegs = 4;                    // chain tables and the analytic plan's pricing: at most four blocks per workgroup
+
+void price(Plan &pl, const int (*wg_blocks)[kChainSegs], int n_wgs, int64_t bh, int cus) {
     const int waves = pl.pp.waves;
     const int64_t wgs = bh * n_wgs;
     const bool shared = waves == 4 && wgs > cus;                    // a second 4-wave workgroup on the same CU
     double longest = 0.0;
     for (int j = 0; j < n_wgs; ++j) {
-        const int l = busiest_simd(wg_blocks[j], kMaxSeg, pl.pp.chain, waves);
+        const int l = busiest_simd(wg_blocks[j], kChainSegs, pl.pp.chain, waves);
         longest = fmax(longest, kFixedCycles + (shared ? 2.0 : 1.0) * l * kUnitCycles);
     }
     pl.n_wgs = n_wgs;
@@ -84,13 +87,13 @@ void price(Plan &pl, const int (*wg_blocks)[kMaxSeg], int n_wgs, int64_t bh, int
 
 bool chain_table_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
     if (nqb > 255) return false;
-    int blocks[kMaxTableWgs][kMaxSeg] = {}, units[kMaxTableWgs] = {}, free_waves[kMaxTableWgs], nseg[kMaxTableWgs] = {};
+    int blocks[kMaxTableWgs][kChainSegs] = {}, units[kMaxTableWgs] = {}, free_waves[kMaxTableWgs], nseg[kMaxTableWgs] = {};
     int n_wgs = 0;
     for (int n = nqb; n >= 1; --n) {
         const int g = (n + c - 1) / c;
         int pick = -1;
         for (int j = 0; j < n_wgs; ++j)
-            if (free_waves[j] >= g && nseg[j] < kMaxSeg && (pick < 0 || units[j] < units[pick])) pick = j;
+            if (free_waves[j] >= g && nseg[j] < kChainSegs && (pick < 0 || units[j] < units[pick])) pick = j;
         if (pick < 0) {
             if (n_wgs == kMaxTableWgs) return false;
             pick = n_wgs++;
@@ -105,20 +108,21 @@ bool chain_table_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) 
         int m = i;
         for (int j = i + 1; j < n_wgs; ++j) if (units[j] > units[m]) m = j;
         if (m != i) {
-            for (int t = 0; t < kMaxSeg; ++t) { const int x = blocks[i][t]; blocks[i][t] = blocks[m][t]; blocks[m][t] = x; }
+            for (int t = 0; t < kChainSegs; ++t) { const int x = blocks[i][t]; blocks[i][t] = blocks[m][t]; blocks[m][t] = x; }
             const int x = units[i]; units[i] = units[m]; units[m] = x;
         }
     }
     pl.pp = pack_plan(nqb, waves, c);
     pl.pp.wgs_per_bh = n_wgs;
     pl.use_table = true;
+    pl.segs = kChainSegs;
     pl.family = "chain table";
     for (int j = 0; j < n_wgs; ++j) {
         int w0 = 0;
-        for (int t = 0; t < kMaxSeg; ++t) {
+        for (int t = 0; t < kChainSegs; ++t) {
             const int n = blocks[j][t], g = n ? (n + c - 1) / c : 0;
-            pl.table[j * kTableWords + 2 * t] = n ? seg_word0(n, 0, n, ((1u << g) - 1u) << w0) : 0u;
-            pl.table[j * kTableWords + 2 * t + 1] = 0u;
+            pl.table[j * 2 * kChainSegs + 2 * t] = n ? seg_word0(n, 0, n, ((1u << g) - 1u) << w0) : 0u;
+            pl.table[j * 2 * kChainSegs + 2 * t + 1] = 0u;
             w0 += g;
         }
     }
@@ -131,8 +135,8 @@ void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
     pl.use_table = false;
     pl.family = "analytic";
     // priced from its closed form: the alone blocks nqb, nqb-1, ..., then the pairs (R - t, t + 1)
-    std::vector<int> flat((size_t)pl.pp.wgs_per_bh * kMaxSeg, 0);
-    int (*blocks)[kMaxSeg] = reinterpret_cast<int (*)[kMaxSeg]>(flat.data());
+    std::vector<int> flat((size_t)pl.pp.wgs_per_bh * kChainSegs, 0);
+    int (*blocks)[kChainSegs] = reinterpret_cast<int (*)[kChainSegs]>(flat.data());
     for (int j = 0; j < pl.pp.wgs_per_bh; ++j) {
         if (j < pl.pp.n_alone) blocks[j][0] = nqb - j;
         else { const int t = j - pl.pp.n_alone; blocks[j][0] = pl.pp.n_paired - t; if (t + 1 != blocks[j][0]) blocks[j][1] = t + 1; }
@@ -141,7 +145,7 @@ void analytic_plan(Plan &pl, int nqb, int waves, int c, int64_t bh, int cus) {
 }
 
 // Experiments only (tests/helpers/libcmhsa_hip_planenv.so and tools/ build the library with -DCMHSA_PLAN_ENV):
-// CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force an analytic / chain plan, CMHSA_WAVES=1 one-wave workgroups
+// CMHSA_WAVES=4|8, CMHSA_CHAIN=c, CMHSA_TABLE=0|1 force an analytic / chain plan, CMHSA_SEGS=4|8 the packed tables' segment count, CMHSA_WAVES=1 one-wave workgroups
 // (CMHSA_NOWP=1: never those; CMHSA_LPT=0: pairs of blocks only, CMHSA_LPT=G: one block per wave, longest first in groups
 // of G (b,h)s), CMHSA_PACKED=L forces a packed plan
 // with SIMD cap L (CMHSA_SPLIT=0|1: without / with blocks split across workgroups), CMHSA_VERBOSE prints the choice.
@@ -174,13 +178,31 @@ struct Rng {                                     // xorshift64*: deterministic, 
     double next() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return (double)((s * 2685821657736338717ull) >> 11) / 9007199254740992.0; }
 };
 
+// Planning-time budget: choose_plan() grants a number of slot-set evaluations; when they are used up every further
+// packing attempt fails at once and the candidates found so far compete (long sequences on one or two (b,h)s would
+// otherwise spend hundreds of milliseconds packing 255 blocks into 64 workgroups for every cap tried).
+thread_local int64_t g_pack_budget = 0;
+
 // best set of g free slots of `wg` for an item of cnt units under `cap`; 0 if none
 unsigned best_slots(const PackWg &wg, int cnt, int g, int cap) {
+    if (g_pack_budget <= 0) return 0;
+    g_pack_budget -= 1;
+    // the 8-bit masks by population count, ascending (at most C(8,4) = 70 per count)
+    static const struct ByCount {
+        unsigned char mask[9][70];
+        int n[9];
+        ByCount() {
+            for (int c = 0; c < 9; ++c) n[c] = 0;
+            for (unsigned m = 1; m < 256; ++m) { const int c = __builtin_popcount(m); mask[c][n[c]++] = (unsigned char)m; }
+        }
+    } by_count;
+    if (g < 1 || g > 8) return 0;
     unsigned best = 0;
     int best_score = 1 << 30;
     const unsigned free_mask = ~wg.used & 0xffu;
-    for (unsigned m = 1; m < 256; ++m) {
-        if ((m & free_mask) != m || __builtin_popcount(m) != g) continue;
+    for (int mi = 0; mi < by_count.n[g]; ++mi) {
+        const unsigned m = by_count.mask[g][mi];
+        if ((m & free_mask) != m) continue;
         int load[8], i = 0, score = 0;
         bool ok = true;
         for (int w = 0; w < 8; ++w) {
@@ -201,7 +223,7 @@ unsigned best_slots(const PackWg &wg, int cnt, int g, int cap) {
 
 // wave_share: preferred units per wave as a fraction of the SIMD cap: 1/2 = two equal waves per SIMD; up to 1 = one
 // long chain per SIMD (fewer waves per block, for plans with few workgroups per (b,h), where wave slots are scarce)
-bool pack_attempt(int nqb, int L, bool allow_split, double psplit, double wave_share, Rng &rng, int g_max, std::vector<PackWg> &wgs, int &n_splits) {
+bool pack_attempt(int nqb, int L, bool allow_split, double psplit, double wave_share, Rng &rng, int g_max, int max_seg, std::vector<PackWg> &wgs, int &n_splits) {
     const int Lp = L - 1;
     std::vector<PackItem> items;
     n_splits = 0;
@@ -224,6 +246,7 @@ bool pack_attempt(int nqb, int L, bool allow_split, double psplit, double wave_s
     std::stable_sort(items.begin(), items.end(), [](const PackItem &a, const PackItem &b) { return a.key < b.key; });
     wgs.clear();
     for (const PackItem &it : items) {
+        if (g_pack_budget <= 0) return false;
         const bool part = it.split >= 0;
         // candidates: existing workgroups, fullest first, then a new one
         std::vector<int> order(wgs.size());
@@ -232,9 +255,10 @@ bool pack_attempt(int nqb, int L, bool allow_split, double psplit, double wave_s
         order.push_back(-1);
         bool placed = false;
         for (int j : order) {
+            g_pack_budget -= 1;                                          // (a visit costs about one slot-set evaluation)
             PackWg fresh;
             PackWg &wg = j < 0 ? fresh : wgs[j];
-            if (wg.nseg >= kMaxSeg) continue;
+            if (wg.nseg >= max_seg) continue;
             const int cap = (wg.partial || part) ? Lp : L;
             if (part && !wg.partial) {
                 bool fits = true;
@@ -290,10 +314,18 @@ bool pack_attempt(int nqb, int L, bool allow_split, double psplit, double wave_s
     return true;
 }
 
-bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus, bool eager_split = false) {
+// max_seg = 4 or 8 segments per workgroup (8: at most 32 workgroups per (b,h) fit the table; the kernel stages eight query
+// blocks, 130 KiB of LDS)
+bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus, bool eager_split = false, int max_seg = 4) {
     if (nqb > 255 || bh > cus) return false;
-    const int g_max = (int)min((int64_t)kMaxTableWgs, (int64_t)cus / bh);
-    Rng rng{0x9E3779B97F4A7C15ull ^ ((uint64_t)nqb << 32) ^ ((uint64_t)L << 16) ^ (uint64_t)g_max ^ (allow_split ? 0x5555ull : 0ull)
+    const int g_max = (int)min((int64_t)(kTableSize / (2 * max_seg)), (int64_t)cus / bh);
+    {   // cannot fit whatever the order: more blocks than segment slots, or more waves needed than there are
+        int64_t waves_needed = 0;
+        for (int n = 1; n <= nqb; ++n) waves_needed += (n + L - 1) / L;
+        if (nqb > (int64_t)g_max * max_seg || waves_needed > (int64_t)g_max * 8) return false;
+    }
+    g_pack_budget = 20000;                       // slot-set evaluations for this (cap, segments, split) candidate: a few ms
+    Rng rng{0x9E3779B97F4A7C15ull ^ ((uint64_t)nqb << 32) ^ ((uint64_t)L << 16) ^ (uint64_t)g_max ^ (allow_split ? 0x5555ull : 0ull) ^ ((uint64_t)(max_seg == 8) << 60)
             ^ ((uint64_t)env_int("CMHSA_SEED", 0) << 40)};
     // Up to four packings that fit are priced and the cheapest is kept (the first on ties): a workgroup's time =
     // kFixed + its busiest SIMD's units * kUnit + kHandoff for the first PART it holds, 0.3 kHandoff for each further one
@@ -319,7 +351,7 @@ bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus
         const double psplit = !allow_split ? 0.0 : eager_split ? 0.2 : t < 6 ? 0.0 : 0.04 * (1 + (t - 6) / 6);
         // two equal waves per SIMD first (measured best on BASELINE config 2); longer chains only when that cannot be packed
         const double wave_share = allow_split ? (t < 12 ? 0.5 : t % 2 ? 0.75 : 1.0) : (t < 3 ? 0.5 : t < 6 ? 0.75 : 1.0);
-        if (!pack_attempt(nqb, L, allow_split, psplit, wave_share, rng, g_max, cand, cand_splits)) continue;
+        if (!pack_attempt(nqb, L, allow_split, psplit, wave_share, rng, g_max, max_seg, cand, cand_splits)) continue;
         if (bh * cand_splits * 2 > (int64_t)kWsMaxParts || bh * cand_splits * 4 > (int64_t)kWsCounterBytes) continue;
         double worst, sum;
         price_wgs(cand, worst, sum);
@@ -333,6 +365,7 @@ bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus
     pl.pp = pack_plan(nqb, 8, (L + 1) / 2);
     pl.pp.wgs_per_bh = (int)wgs.size();
     pl.use_table = true;
+    pl.segs = max_seg;
     pl.family = n_splits ? "packed table, blocks split across workgroups" : "packed table";
     pl.n_wgs = (int)wgs.size();
     pl.simd_cap = L;
@@ -341,15 +374,15 @@ bool packed_plan(Plan &pl, int nqb, int L, bool allow_split, int64_t bh, int cus
     pl.single_round = true;
     for (int j = 0; j < pl.n_wgs; ++j) {
         const PackWg &wg = wgs[j];
-        for (int t = 0; t < kMaxSeg; ++t) {
+        for (int t = 0; t < max_seg; ++t) {
             unsigned w0 = 0, w1 = 0;
             if (t < wg.nseg) {
                 w0 = seg_word0(wg.seg_n[t], wg.seg_lo[t], wg.seg_cnt[t], wg.seg_mask[t]);
                 if (wg.seg_split[t] >= 0)        // first slot | part index << 8 | parts << 12 | split id << 16
                     w1 = (unsigned)(2 * wg.seg_split[t]) | ((wg.seg_lo[t] ? 1u : 0u) << 8) | (2u << 12) | ((unsigned)wg.seg_split[t] << 16);
             }
-            pl.table[j * kTableWords + 2 * t] = w0;
-            pl.table[j * kTableWords + 2 * t + 1] = w1;
+            pl.table[j * 2 * max_seg + 2 * t] = w0;
+            pl.table[j * 2 * max_seg + 2 * t + 1] = w1;
         }
     }
     pl.cycles = best_max;
@@ -394,18 +427,35 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
             }
         }
     }
-    // packed plans: the smallest SIMD caps that could hold the work, without and (given a workspace) with split blocks
-    if (!forced_old && nqb <= 255 && bh <= cus) {
-        const int g_max = (int)min((int64_t)kMaxTableWgs, (int64_t)cus / bh);
+    // packed plans: the smallest SIMD caps that could hold the work, without and (given a workspace) with split blocks;
+    // four segments per workgroup first, then eight (more blocks per workgroup: long sequences on few (b,h)s, where four
+    // segments x the workgroups the CUs allow cannot hold every block; the eight-segment kernel stages eight query blocks)
+    static const int forced_segs = env_int("CMHSA_SEGS", 0);
+    for (int max_seg = 4; max_seg <= 8 && !forced_old && nqb <= 255 && bh <= cus; max_seg += 4) {
+        if (forced_segs && forced_segs != max_seg) continue;
+        const int g_max = (int)min((int64_t)(kTableSize / (2 * max_seg)), (int64_t)cus / bh);
+        if (g_max < 1) continue;
         const int64_t total = (int64_t)nqb * (nqb + 1) / 2;
         const int l_min = forced_packed ? forced_packed : (int)max((int64_t)1, (total + 4 * g_max - 1) / (4 * g_max));
-        const int l_max = forced_packed ? forced_packed : l_min + 3;
-        for (int L = l_min; L <= l_max; ++L) {
+        // caps tried: the four smallest, then -- the greedy packer gives up above ~93 % fill, which long sequences reach
+        // (96 blocks on 21 workgroups) -- up to a fifth more in coarser steps, stopping at the first that packs
+        int caps[8], n_caps = 0;
+        for (int i = 0; i < 4; ++i) caps[n_caps++] = l_min + i;
+        for (int pct = 106; pct <= 121 && !forced_packed; pct += 5) {
+            const int L = (l_min * pct + 99) / 100;
+            if (L > caps[n_caps - 1]) caps[n_caps++] = L;
+        }
+        if (forced_packed) n_caps = 1;
+        bool packed_found = false;
+        for (int ci = 0; ci < n_caps && !(packed_found && ci >= 4); ++ci) {
+            const int L = caps[ci];
             for (int split = 0; split <= (allow_split ? 1 : 0); ++split) {
                 if (forced_split >= 0 && forced_split != split && (allow_split || forced_split == 0)) continue;
                 Plan pl;
-                if (!packed_plan(pl, nqb, L, split != 0, bh, cus, split != 0 && forced_split == 1)) continue;
+                if (!packed_plan(pl, nqb, L, split != 0, bh, cus, split != 0 && forced_split == 1, max_seg)) continue;
                 if (split && !pl.splits_per_bh) continue;            // the same plan as split = 0
+                packed_found = true;
+                if (max_seg == 8) pl.cycles += 1500.0;               // twice the query staging, a longer segment decode
                 if (!have || pl.cycles < best.cycles * 0.98) { best = pl; have = true; }
             }
         }
@@ -489,8 +539,8 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
     if (env_int("CMHSA_VERBOSE", 0) > 1 && best.use_table)
         for (int j = 0; j < best.n_wgs; ++j) {
             fprintf(stderr, "  wg %2d:", j);
-            for (int t = 0; t < kMaxSeg; ++t) {
-                const unsigned w0 = best.table[j * kTableWords + 2 * t], w1 = best.table[j * kTableWords + 2 * t + 1];
+            for (int t = 0; t < best.segs; ++t) {
+                const unsigned w0 = best.table[j * 2 * best.segs + 2 * t], w1 = best.table[j * 2 * best.segs + 2 * t + 1];
                 if (w0 & 255u) fprintf(stderr, "  block %u units [%u,+%u) waves %02x%s", w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 ? " PART" : "");
             }
             fprintf(stderr, "\n");

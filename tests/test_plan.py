@@ -7,7 +7,7 @@ workgroups, one-wave workgroups in pairs or longest first -- the kernel is only 
   * every unit [0, n) of every query block n = 1..nqb is covered EXACTLY once (whole blocks, or parts that tile it),
   * a workgroup's segments use disjoint sets of its waves, and no segment has more waves than units (the kernel's
     "every active wave owns at least one unit"),
-  * table plans stay inside their encoding (n <= 255, <= 64 workgroups per (b,h), <= 4 segments per workgroup),
+  * table plans stay inside their encoding (n <= 255; 4 segments per workgroup and <= 64 workgroups per (b,h), or 8 and 32),
   * parts carry consistent bookkeeping (part index, part count, slots, split id inside the workspace the plan asks for),
   * the grid covers every (b,h) and stays inside HIP's limits.
 
@@ -44,7 +44,7 @@ def check_plan(B, T, H, with_ws, cus):
     else:
         assert plan["grid_x"] * plan["grid_z"] == bh, tag       # only the longest-first grid is padded
     if plan["use_table"]:
-        assert plan["segs"] == 4 and plan["wgs_per_bh"] <= 64 and nqb <= 255, tag
+        assert plan["segs"] in (4, 8) and plan["wgs_per_bh"] * plan["segs"] <= 256 and nqb <= 255, tag   # the table holds 512 words
     if not with_ws:
         assert plan["parts_per_bh"] == 0 and plan["splits_per_bh"] == 0 and plan["workspace_256"] == 0, tag
     assert plan["workspace_256"] * 256 <= WORKSPACE_BYTES, tag

@@ -150,7 +150,9 @@ def test_torch_op_uses_its_per_stream_workspace(gpu_device):
 
 @pytest.mark.parametrize("env", [{"CMHSA_PACKED": "7", "CMHSA_SPLIT": "1"}, {"CMHSA_PACKED": "8", "CMHSA_SPLIT": "1"},
                                  {"CMHSA_PACKED": "5", "CMHSA_SPLIT": "1"}, {"CMHSA_PACKED": "9", "CMHSA_SPLIT": "0"},
-                                 {"CMHSA_PACKED": "12", "CMHSA_SPLIT": "1"}])
+                                 {"CMHSA_PACKED": "12", "CMHSA_SPLIT": "1"},
+                                 {"CMHSA_PACKED": "9", "CMHSA_SPLIT": "1", "CMHSA_SEGS": "8"},
+                                 {"CMHSA_PACKED": "14", "CMHSA_SPLIT": "0", "CMHSA_SEGS": "8"}])
 def test_forced_packed_plans_in_a_child_process(env):
     """Packed plans with a forced SIMD cap (and forced splitting) over shapes the cost model would give other plans:
     through the plan-forcing TEST build of the kernel sources, every (batch, head) against the f64 oracle."""
