@@ -464,6 +464,27 @@ def test_random_shapes_fuzz(gpu_device):
     assert worst <= 1e-5, worst          # randn inputs: observed ~1e-6
 
 
+@pytest.mark.parametrize("B,H,T", [(1, 16, 2048), (1, 12, 3072), (1, 25, 2048), (1, 12, 4000), (2, 12, 2048), (1, 16, 3000)])
+def test_single_long_prompts(B, H, T, gpu_device):
+    """Single long prompts (packed tables with eight segments per workgroup where they fit, the analytic plan or wave pairs
+    beyond): the whole output against the oracle's formula in float64, every element written, strided (packed-QKV) inputs,
+    with the workspace and without it."""
+    torch.manual_seed(T + H)
+    d = 64 * H
+    qkv = torch.randn(B, T, 3 * d, device=gpu_device)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    want = oracle.naive_attention_torch(q.double(), k.double(), v.double(), H)
+    ws = cmhsa.Workspace(gpu_device)
+    for workspace in (None, ws):
+        out = torch.full((B, T, d), float("nan"), device=gpu_device)
+        cmhsa.attention_fwd(q, k, v, H, out=out, workspace=workspace)
+        assert torch.isfinite(out).all()
+        assert (out.double() - want).abs().max().item() <= 1e-5, (B, H, T, workspace is not None)
+    if (B, H, T) in ((1, 16, 2048), (1, 12, 3072)):
+        plan = cmhsa.plan_dump(B, T, H, True)
+        assert plan["use_table"] and plan["segs"] == 8, plan
+
+
 def test_random_larger_grids_fuzz(gpu_device):
     """Thirty seeded random shapes with 1 500 to 40 000 (batch, head, query block) triples -- the range where the planner
     moves between the analytic plan, wave pairs and longest-first one-wave workgroups -- ragged lengths, B*H mostly not
