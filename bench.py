@@ -73,6 +73,9 @@ def parse_args():
                     help="device ramp before the warm-up steps: milliseconds of back-to-back launches of the workload (0 = none)")
     ap.add_argument("--gen-budget", type=float, default=120.0,
                     help="seconds the generation legs (GPT2 512-token runs, config 1 on the CPU, config 4 sample) may take in all")
+    ap.add_argument("--extras-limit", type=float, default=420.0,
+                    help="seconds the legs after the headline may take before the line is printed without them (a stalled collective "
+                         "or a failed rank must not cost the headline measurement)")
     return ap.parse_args()
 
 
@@ -659,20 +662,53 @@ def main() -> None:
         faulthandler.dump_traceback_later(int(os.environ["CMHSA_BENCH_WATCHDOG"]), exit=True)
     b = Bench(args)
     result = b.headline()
-    if not args.no_extras:
-        t0 = time.perf_counter()
-        if b.world == 1 and args.workload == "config2":
-            result["other_workloads"] = b.other_workloads()
-            gen = b.generation(args.gen_budget)
-            result["other_workloads"]["generation"] = gen
-            # the N = 1 point of the data-parallel config-4 sample (the N > 1 lines carry the same leg)
-            result["config4_dp"] = b.config4_dp_leg(args.gen_budget - gen["seconds_spent"])
-        if b.world > 1 and args.workload == "config2":
-            result["config5"] = b.config5_leg()
-            result["config4_dp"] = b.config4_dp_leg(args.gen_budget)
-        result["extras_seconds"] = round(time.perf_counter() - t0, 1)
     if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], b.torch)
+    if not args.no_extras:
+        # The legs below run collectives and minutes of generation that the headline does not depend on.  If they are
+        # not done after --extras-limit seconds (a rank died inside a leg, a collective stalled) every rank leaves on
+        # its own and rank 0 prints the line as it stood after the headline.
+        import threading
+
+        headline_only = json.dumps({**result, "extras": f"abandoned: not finished after {args.extras_limit:.0f} s; "
+                                                          "the figures of this line were measured before them"})
+        extras_done = threading.Event()
+
+        def leave_without_extras() -> None:
+            if extras_done.wait(args.extras_limit):
+                return
+            if b.rank == 0:
+                print(headline_only, flush=True)
+            os._exit(0)
+
+        threading.Thread(target=leave_without_extras, daemon=True).start()
+
+        def leg(fn, *a):
+            try:
+                return fn(*a)
+            except Exception as e:                               # noqa: BLE001 -- recorded in the line, the headline stands
+                return f"failed: {type(e).__name__}: {e}"[:300]
+
+        t0 = time.perf_counter()
+        if os.environ.get("CMHSA_BENCH_STALL_EXTRAS"):           # tests only: stands in for a collective that never returns
+            time.sleep(1e6)
+        if b.world == 1 and args.workload == "config2":
+            result["other_workloads"] = leg(b.other_workloads)
+            gen = leg(b.generation, args.gen_budget)
+            spent = gen["seconds_spent"] if isinstance(gen, dict) else args.gen_budget
+            if isinstance(result["other_workloads"], dict):
+                result["other_workloads"]["generation"] = gen
+            else:
+                result["generation"] = gen
+            # the N = 1 point of the data-parallel config-4 sample (the N > 1 lines carry the same leg)
+            result["config4_dp"] = leg(b.config4_dp_leg, args.gen_budget - spent)
+        if b.world > 1 and args.workload == "config2":
+            result["config5"] = leg(b.config5_leg)
+            result["config4_dp"] = leg(b.config4_dp_leg, args.gen_budget)
+        result["extras_seconds"] = round(time.perf_counter() - t0, 1)
+        if b.dist is not None:
+            b.dist.barrier()                                     # (still under the limit: a rank that failed a leg may be missing)
+        extras_done.set()
     if b.dist is not None:
         b.dist.barrier()
         b.dist.destroy_process_group()

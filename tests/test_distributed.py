@@ -144,6 +144,29 @@ def test_bench_self_launches_two_ranks_in_rehearsal_mode():
 
 
 @pytest.mark.gpu
+def test_bench_prints_the_headline_when_the_later_legs_stall():
+    """The legs after the headline (collectives, minutes of generation) run under --extras-limit: when they do not
+    finish -- here a stand-in that never returns, on both ranks of a rehearsal run -- every rank leaves on its own and
+    rank 0 still prints the line with the headline measurement, exit code 0."""
+    import json
+    import subprocess
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CMHSA_BENCH_BACKEND"] = "gloo"
+    env["CMHSA_BENCH_STALL_EXTRAS"] = "1"
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--ramp-ms", "5",
+                        "--extras-limit", "5"], capture_output=True, text=True, env=env, timeout=200)
+    assert r.returncode == 0 and time.perf_counter() - t0 < 150, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["extras"].startswith("abandoned") and "config5" not in line
+
+
+@pytest.mark.gpu
 def test_bench_self_launch_fails_fast_when_a_rank_has_no_gpu():
     """`--gpus 2` with RCCL on a box with ONE GPU: rank 1 has no device and exits; the launcher must end rank 0 (which would
     otherwise sit in the rendezvous until torch's time-out) and report, within seconds."""
