@@ -581,15 +581,19 @@ class Bench:
         comp_ms = span(lambda: sa.head_sharded_attention(Q, K, V, H_total, compute, gather=False))
         ag_ms = span((lambda: dist.all_gather_into_tensor(flat, slab)) if self.backend == "nccl" else (lambda: sa.all_gather_dim0(slab, world)))
         e2e_ms = span(lambda: sa.head_sharded_attention(Q, K, V, H_total, compute))
-        comp_ms, ag_ms, e2e_ms = self.max_over_ranks(comp_ms, ag_ms, e2e_ms)
+        # pipelined over batch pieces: gather + permute of piece i on a second stream beside the kernel of piece i+1
+        piped_ms = {c: span(lambda c=c: sa.head_sharded_attention(Q, K, V, H_total, compute, chunks=c)) for c in (2, 4) if c <= B}
+        comp_ms, ag_ms, e2e_ms, *piped = self.max_over_ranks(comp_ms, ag_ms, e2e_ms, *piped_ms.values())
+        piped_ms = dict(zip(piped_ms, piped))
         full = sa.head_sharded_attention(Q, K, V, H_total, compute)
+        piped_diff = max((float((sa.head_sharded_attention(Q, K, V, H_total, compute, chunks=c) - full).abs().max()) for c in piped_ms), default=0.0)
         # parity of the gathered result: one head this rank did NOT compute, against the f64 oracle
         from oracle import naive_attention as oracle
         h = ((self.rank + 1) % world) * per
         sl = slice(64 * h, 64 * h + 64)
         want = oracle.naive_attention_f64(Q[0, :, sl].cpu().numpy(), K[0, :, sl].cpu().numpy(), V[0, :, sl].cpu().numpy(), 1)
         err = float(abs(full[0, :, sl].cpu().numpy() - want).max())
-        (err,) = self.max_over_ranks(err)
+        err, piped_diff = self.max_over_ranks(err, piped_diff)
         recv = (world - 1) * slab.numel() * 4
         total_flops = self.cmhsa.algorithmic_flops(B, T, H_total, 64)
         return {"via": "sharded_attention.head_sharded_attention(compute=cmhsa.attention_fwd)",
@@ -599,6 +603,8 @@ class Bench:
                 "all_gather_GBps_received_per_rank": round(recv / (ag_ms * 1e-3) / 1e9, 1),
                 "end_to_end_ms_incl_permute": round(e2e_ms, 4),
                 "end_to_end_tflops_all_gpus": round(total_flops / (e2e_ms * 1e-3) / 1e12, 2),
+                "end_to_end_ms_pipelined_over_batch_pieces": {str(c): round(ms, 4) for c, ms in piped_ms.items()},
+                "pipelined_max_abs_diff_vs_one_gather": piped_diff,
                 "gathered_max_abs_err_vs_f64_oracle": err,
                 "note": "GB/s is per rank over all its links together; the per-link rate depends on how RCCL routes the collective"}
 

@@ -43,18 +43,36 @@ def head_slab(t: torch.Tensor, num_heads: int, rank: int, world: int, head_dim: 
     return t[..., rank * per * head_dim:(rank + 1) * per * head_dim]
 
 
+_side_streams: dict = {}
+
+
+def _side_stream(device: torch.device) -> "torch.cuda.Stream":
+    """One extra HIP stream per device for the collectives and copies that overlap the attention kernels."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def head_sharded_attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: int,
                            compute: Callable[[torch.Tensor, torch.Tensor, torch.Tensor, int], torch.Tensor],
-                           group=None, head_dim: int = 64, gather: bool = True):
+                           group=None, head_dim: int = 64, gather: bool = True, chunks: int = 1):
     """Q, K, V: full (B, T, H*head_dim) tensors present on every rank (or at least this rank's head columns valid).
     Returns the full (B, T, H*head_dim) context on every rank (gather=True), else this rank's slab.
 
-    The all-gather writes into a (W, B, T, slab) buffer (contiguous per-rank slabs, one collective), which is then
-    viewed back to (B, T, H*head_dim); slabs are column blocks of the output, so the permute is a strided copy."""
+    chunks = 1: ONE all-gather into a (W, B, T, slab) buffer (contiguous per-rank slabs), which is then viewed back to
+    (B, T, H*head_dim); slabs are column blocks of the output, so the permute is a strided copy.
+
+    chunks > 1 (gather only): the batch is cut into that many pieces and the pieces are pipelined -- the all-gather and
+    the permute of piece i run on a second HIP stream while the kernel computes piece i+1 on the caller's stream (over
+    xGMI the gather of config 5's slabs takes longer than computing them, so end to end this approaches the gather time
+    alone).  The result is ordered on the caller's stream like any other torch op."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     per = num_heads // world
     q, k, v = (head_slab(t, num_heads, rank, world, head_dim) for t in (Q, K, V))
+    if gather and chunks > 1 and Q.dim() == 3 and Q.shape[0] > 1:
+        return _head_sharded_pipelined(q, k, v, per, compute, world, group, min(chunks, Q.shape[0]))
     slab = compute(q, k, v, per)                                    # (B, T, per*head_dim), contiguous
     if not gather:
         return slab
@@ -64,6 +82,38 @@ def head_sharded_attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, nu
     buf = flat.view((world,) + tuple(slab.shape))
     # (W, B, T, per*hd) -> (B, T, W, per*hd) -> (B, T, H*hd)
     return buf.movedim(0, -2).reshape(*slab.shape[:-1], world * slab.shape[-1])
+
+
+def _head_sharded_pipelined(q, k, v, per, compute, world, group, chunks):
+    B, T, width = q.shape
+    out = torch.empty((B, T, world * width), dtype=q.dtype, device=q.device)
+    base, extra = divmod(B, chunks)
+    on_gpu = q.is_cuda
+    if on_gpu:
+        main = torch.cuda.current_stream(q.device)
+        side = _side_stream(q.device)
+        side.wait_stream(main)                                      # `out` (allocated on main) and earlier users of the side stream
+        out.record_stream(side)
+    lo = 0
+    for c in range(chunks):
+        hi = lo + base + (1 if c < extra else 0)
+        slab = compute(q[lo:hi], k[lo:hi], v[lo:hi], per).contiguous()
+
+        def gather_and_place(slab=slab, lo=lo, hi=hi):
+            flat = all_gather_dim0(slab, world, group)               # (W * b, T, width)
+            out[lo:hi].view(hi - lo, T, world, width).copy_(flat.view(world, hi - lo, T, width).movedim(0, 2))
+
+        if on_gpu:
+            side.wait_stream(main)                                   # this piece's kernel
+            slab.record_stream(side)
+            with torch.cuda.stream(side):
+                gather_and_place()
+        else:
+            gather_and_place()
+        lo = hi
+    if on_gpu:
+        main.wait_stream(side)
+    return out
 
 
 def batch_sharded_attention(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, num_heads: int,

@@ -43,6 +43,11 @@ def _worker(rank, world, port, fn_name, out_dir):
             got = sa.head_sharded_attention(Q, K, V, H, compute)
             mine = sa.head_sharded_attention(Q, K, V, H, compute, gather=False)
             assert torch.equal(mine, got[..., rank * 128:(rank + 1) * 128])
+        elif fn_name == "head_pipelined":                                        # 3 batch rows in 2 pieces, then one row per piece
+            got = sa.head_sharded_attention(Q, K, V, H, compute, chunks=2)
+            assert got.shape == want.shape and got.is_contiguous()
+            again = sa.head_sharded_attention(Q, K, V, H, compute, chunks=8)
+            assert torch.allclose(again, got, atol=1e-6)
         elif fn_name == "batch":
             got = sa.batch_sharded_attention(Q, K, V, H, compute, gather=True)
             local = sa.batch_sharded_attention(Q, K, V, H, compute)
@@ -59,7 +64,7 @@ def _worker(rank, world, port, fn_name, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fn_name", ["head", "batch", "bad_heads"])
+@pytest.mark.parametrize("fn_name", ["head", "head_pipelined", "batch", "bad_heads"])
 def test_two_rank_sharding_matches_single_device(fn_name, tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, fn_name, str(tmp_path)), nprocs=world, join=True)
@@ -104,8 +109,16 @@ def _gpu_worker(rank, world, port, backend, out_dir):
         per = d // world
         assert torch.equal(mine, got[..., rank * per:(rank + 1) * per])
         got_b = sa.batch_sharded_attention(Q, K, V, H, compute, gather=True)
+        # pipelined over batch pieces (gather + permute on a second stream), several calls queued back to back
+        Q4, K4, V4 = (t.repeat(3, 1, 1)[:5] for t in (Q, K, V))
+        whole = sa.head_sharded_attention(Q4, K4, V4, H, compute)
+        piped = [sa.head_sharded_attention(Q4, K4, V4, H, compute, chunks=c) for c in (2, 3, 5, 2)]
+        for p_out in piped:
+            assert p_out.shape == whole.shape and p_out.is_contiguous()
+            assert float((p_out - whole).abs().max()) <= 1e-5
         want = oracle.naive_attention_f64(Q.cpu().numpy(), K.cpu().numpy(), V.cpu().numpy(), H)
-        err = max(float(np.abs(got.cpu().numpy() - want).max()), float(np.abs(got_b.cpu().numpy() - want).max()))
+        err = max(float(np.abs(got.cpu().numpy() - want).max()), float(np.abs(got_b.cpu().numpy() - want).max()),
+                  float(np.abs(piped[0][:2].cpu().numpy() - want).max()))
         np.save(os.path.join(out_dir, f"gpu_err_{rank}.npy"), np.asarray(err))
     finally:
         dist.destroy_process_group()
