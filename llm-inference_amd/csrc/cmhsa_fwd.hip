@@ -239,15 +239,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         f32x4 qst[kQIters];
 #pragma unroll
         for (int i = 0; i < kQIters; ++i) {
-            const int rg = wave + i * kWaves, sg = rg >> 3, row = 4 * (rg & 7) + sub;    // sg is a compile-time constant
-            const int sq0 = (max(seg_n[sg], 1) - 1) * kQBlock;
-            const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, sq0, N, seg_n[sg] != 0);
-            qst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (row * (int)p.q_rs + chunk * 4) * 4, 0, 0));
+            // wave < kWaves <= 8: segment and row group of (wave + i * kWaves) split at compile time
+            const int sg = (i * kWaves) >> 3, row = 4 * (wave + ((i * kWaves) & 7)) + sub;
+            // plain global loads, two VALU instructions of address arithmetic each (a buffer descriptor per segment cost
+            // ~30 scalar instructions in front of the barrier).  Rows past the end of a ragged last block, and absent
+            // segments, read a valid row instead of zeros: their results are never stored.  q_rs <= 2^24 (host check).
+            const int grow = min((max(seg_n[sg], 1) - 1) * kQBlock + row, N - 1);
+            const float *src = qg + (uint64_t)(uint32_t)grow * (uint32_t)p.q_rs + chunk * 4;
+            qst[i] = *reinterpret_cast<const f32x4 *>(src);
         }
         STAMP(121);
 #pragma unroll
         for (int i = 0; i < kQIters; ++i) {
-            const int rg = wave + i * kWaves, sg = rg >> 3, row = 4 * (rg & 7) + sub;
+            const int sg = (i * kWaves) >> 3, row = 4 * (wave + ((i * kWaves) & 7)) + sub;
             *reinterpret_cast<f32x4 *>(qlds_all + sg * kUnitFloats + row * kHeadDim + ((chunk ^ (row & 15)) << 2)) = qst[i] * kScaleLog2;
         }
     }
