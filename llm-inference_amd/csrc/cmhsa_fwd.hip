@@ -104,7 +104,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t unit_rsrc(const float *head_ba
                                                             bool enable = true) {
     const int valid = min(kKeyUnit, n_rows - row0);       // >= 1 for every unit the kernel touches
     const int bytes = (((valid - 1) * (int)rs + kHeadDim) * 4) & -(int)enable;     // mask, not select: no scalar branch
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(head_base + (int64_t)row0 * rs), 0, bytes, 0x00020000);
+    // row0 >= 0 and rs <= 2^24 (host check): one 32 x 32 -> 64-bit multiply instead of the generic 64-bit one
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(head_base + (uint64_t)(uint32_t)row0 * (uint32_t)rs), 0, bytes, 0x00020000);
 }
 
 // One 32-row x 64-float unit (8 KiB) global -> registers: lane l, step i reads the 16-B chunk
@@ -209,9 +210,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     const int b = udiv_magic(bh, p.num_heads, p.heads_magic), h = bh - b * p.num_heads;
     const int N = p.seq_len;
 
-    const float *qg = p.q + b * p.q_bs + (int64_t)h * kHeadDim;
-    const float *kg = p.k + b * p.k_bs + (int64_t)h * kHeadDim;
-    const float *vg = p.v + b * p.v_bs + (int64_t)h * kHeadDim;
+    const float *qg = p.q + (uint64_t)(uint32_t)b * (uint64_t)p.q_bs + (uint32_t)h * kHeadDim;
+    const float *kg = p.k + (uint64_t)(uint32_t)b * (uint64_t)p.k_bs + (uint32_t)h * kHeadDim;
+    const float *vg = p.v + (uint64_t)(uint32_t)b * (uint64_t)p.v_bs + (uint32_t)h * kHeadDim;
 
     float *wlds = lds + wave * kUnitFloats;      // private to this wave: its current K unit (8 KiB); later its merge image
     float *qlds_all = lds + lds_floats_q(kWaves);                      // shared: the segments' query blocks,
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             for (int u = u_first + seg_waves; u < u_end; u += seg_waves) unit(u, std::false_type{});
             l_run = xhalf_sum(l_run);
         } else {
-            float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
+            float *__restrict__ og = p.o + (uint64_t)(uint32_t)b * (uint64_t)p.o_bs + (uint32_t)h * kHeadDim;
             int u = 1;
             for (;;) {
                 for (; u < u_end; ++u) unit(u, std::false_type{});
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     __syncthreads();
     STAMP(120);
     {
-        float *__restrict__ og = p.o + b * p.o_bs + (int64_t)h * kHeadDim;
+        float *__restrict__ og = p.o + (uint64_t)(uint32_t)b * (uint64_t)p.o_bs + (uint32_t)h * kHeadDim;
         // Items (segment, pair) with item = 8 * segment + pair go round-robin over the waves, so a wave's items share
         // their pair index (8 waves: pair = wave; 4 waves: pair = wave and wave + 4): the image of every wave is read
         // ONCE per pair and serves all segments -- each publishing wave belongs to exactly one of them.
