@@ -525,7 +525,16 @@ class Bench:
             small["kv_cache_opt_in_all_fusions"] = {"seconds": round(t.second_run_seconds, 4), "tokens_generated": n_new,
                                                     "tokens_per_second": round(n_new / t.second_run_seconds, 1),
                                                     "tokens_identical_to_reference_loop": bool(t.tokens[0] == tok_naive)}
-            del kv, model
+            del kv
+            if left() >= 8.0:                       # + the step's linear layers through the few-row HIP kernel (include/gpt2_linear.h)
+                kv = gen.KVCacheGreedyGenerator(model, 1, 512, device=self.dev, few_row_linear=True)
+                t = gen.time_greedy_generation(model, prompt, 512, self.dev, kv)
+                n_new = len(t.tokens[0]) - len(prompt)
+                small["kv_cache_opt_in_all_fusions_few_row_linear"] = {
+                    "seconds": round(t.second_run_seconds, 4), "tokens_generated": n_new, "tokens_per_second": round(n_new / t.second_run_seconds, 1),
+                    "tokens_identical_to_reference_loop": bool(t.tokens[0] == tok_naive)}
+                del kv
+            del model
             torch.cuda.empty_cache()
         res["gpt2"] = small
         del qkv, out, launches

@@ -166,7 +166,8 @@ int cmhsa_fp32_fwd_packed_qkv(const float *qkv, float *o,
  *   o         : (batch, d_model), row stride o_row_stride
  *   pos_dev   : DEVICE pointer to one int32 = index of the new token, 0 <= pos < capacity.  It is read by the
  *               kernel, not by the host, so a captured HIP graph of the step can be replayed for every token; a
- *               value outside [0, capacity) makes the launch a no-op (nothing read, nothing written).
+ *               value outside [0, capacity) reads no key and leaves the caches alone; o is set to zero (so that a
+ *               caller never sees uninitialised memory and needs no fill of its own in front of the launch).
  * HBM/L2-bound; no allocation, no synchronisation; same status codes as cmhsa_fp32_fwd. */
 int cmhsa_fp32_decode_step(const float *qkv_new, int64_t qkv_row_stride,
                            float *k_cache, float *v_cache, int64_t cache_row_stride, int64_t cache_batch_stride,

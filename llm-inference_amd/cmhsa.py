@@ -49,6 +49,8 @@ EXPORTED_SYMBOLS = (
     "gpt2_add_layernorm_algorithmic_bytes",
     "gpt2_embed_f32_fwd",            # include/gpt2_step.h
     "gpt2_greedy_step",
+    "gpt2_linear_rows_f32_fwd",      # include/gpt2_linear.h
+    "gpt2_linear_rows_algorithmic_bytes",
 )
 
 CMHSA_OK = 0
@@ -124,6 +126,10 @@ def load_library() -> ctypes.CDLL:
     lib.gpt2_embed_f32_fwd.argtypes = [vp, i64, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.gpt2_greedy_step.restype = i32
     lib.gpt2_greedy_step.argtypes = [vp, i64, vp, vp, i64, vp, i32, i32, i32, i64, vp]
+    lib.gpt2_linear_rows_f32_fwd.restype = i32
+    lib.gpt2_linear_rows_f32_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.gpt2_linear_rows_algorithmic_bytes.restype = ctypes.c_double
+    lib.gpt2_linear_rows_algorithmic_bytes.argtypes = [i32, i32, i32, i32]
     _lib = lib
     return lib
 

@@ -11,21 +11,13 @@
 
 #include "cmhsa.h"
 #include "gpt2_gelu.h"
+#include "gelu_one.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float kSqrt2OverPi = 0.7978845238685608f;   // sqrtf((float)(2/pi)) = torch.sqrt(torch.tensor(2.0 / torch.pi)), gelu.py:10
-constexpr float kCubic = 0.44715f;                    // gelu.py:11
 constexpr int kThreads = 256;
-
-__device__ __forceinline__ float gelu_one(float x) {
-    const float x3 = __fmul_rn(__fmul_rn(x, x), x);                  // torch.pow(x, 3) == x*x*x
-    const float inner = __fadd_rn(x, __fmul_rn(kCubic, x3));
-    const float t = tanhf(__fmul_rn(kSqrt2OverPi, inner));
-    return __fmul_rn(__fmul_rn(0.5f, x), __fadd_rn(1.0f, t));
-}
 
 // One workgroup = one contiguous 16-KiB chunk (kUnroll x 256 float4): wave-instruction = 1 KiB contiguous, four
 // independent loads in flight per lane.  kStream: non-temporal loads/stores for arrays beyond the Infinity Cache

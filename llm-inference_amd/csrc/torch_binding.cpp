@@ -33,6 +33,7 @@
 #include "gpt2_gelu.h"
 #include "gpt2_layernorm.h"
 #include "gpt2_step.h"
+#include "gpt2_linear.h"
 
 namespace causal_multihead_self_attention {
 
@@ -149,9 +150,8 @@ at::Tensor causal_multihead_self_attention_decode(at::Tensor qkv_new, at::Tensor
     TORCH_CHECK(k_cache.sizes() == v_cache.sizes() && k_cache.strides() == v_cache.strides(), "k_cache and v_cache must have the same shape and strides");
     TORCH_CHECK(k_cache.size(0) == B && k_cache.size(2) == d, "cache shape must be (B, capacity, d_model)");
     TORCH_CHECK(B <= INT32_MAX && cap <= INT32_MAX, "shape exceeds 32-bit indexing");
-    // zero-filled: a pos outside [0, capacity) makes the launch a no-op (include/cmhsa.h), and the op must not hand
-    // back uninitialised memory in that case
-    at::Tensor output = at::zeros({B, d}, qkv_new.options());
+    // no fill in front of the launch: the kernel itself zeroes o when pos is outside [0, capacity) (include/cmhsa.h)
+    at::Tensor output = at::empty({B, d}, qkv_new.options());
     if (output.numel() == 0) return output;
     const c10::hip::HIPGuard guard(qkv_new.device().index());
     const hipStream_t stream = c10::hip::getCurrentHIPStream(qkv_new.device().index()).stream();
@@ -208,6 +208,35 @@ std::tuple<at::Tensor, at::Tensor> add_layer_norm(at::Tensor x, const c10::optio
     return {sum, y};
 }
 
+// Few-row linear layer (include/gpt2_linear.h; torch.nn.functional.linear for x of 1..8 rows, optionally followed by the
+// reference's tanh-GELU, gelu.py:8-12): x (..., k) with at most 8 rows in all, weight (n_out, k), bias (n_out)? -> (..., n_out).
+at::Tensor linear_rows(at::Tensor x, at::Tensor weight, const c10::optional<at::Tensor> &bias, int64_t act) {
+    TORCH_CHECK(x.is_cuda() && weight.is_cuda() && x.dtype() == at::kFloat && weight.dtype() == at::kFloat, "x and weight must be float32 CUDA tensors");
+    TORCH_CHECK(x.dim() >= 1 && weight.dim() == 2 && x.size(-1) == weight.size(1), "x must be (..., k) and weight (n_out, k)");
+    TORCH_CHECK(weight.device() == x.device(), "x and weight must be on the same device");
+    const int64_t k = weight.size(1), n_out = weight.size(0);
+    const at::Tensor xc = x.contiguous(), wc = weight.stride(1) == 1 ? weight : weight.contiguous();
+    const int64_t rows = k ? xc.numel() / k : 0;
+    TORCH_CHECK(rows <= GPT2_LINEAR_MAX_ROWS, "linear_rows is for at most ", GPT2_LINEAR_MAX_ROWS, " rows of x; use torch.nn.functional.linear beyond");
+    at::Tensor bc;
+    if (bias.has_value()) {
+        TORCH_CHECK(bias->is_cuda() && bias->dtype() == at::kFloat && bias->numel() == n_out && bias->device() == x.device(),
+                    "bias must be a float32 CUDA tensor with n_out elements on x's device");
+        bc = bias->contiguous();
+    }
+    std::vector<int64_t> out_sizes(x.sizes().begin(), x.sizes().end());
+    out_sizes.back() = n_out;
+    at::Tensor y = at::empty(out_sizes, x.options().memory_format(c10::MemoryFormat::Contiguous));
+    if (y.numel() == 0) return y;
+    TORCH_CHECK(n_out <= INT32_MAX && k <= INT32_MAX, "shape exceeds 32-bit indexing");
+    const c10::hip::HIPGuard guard(x.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(x.device().index()).stream();
+    const int rc = gpt2_linear_rows_f32_fwd(xc.data_ptr<float>(), k, wc.data_ptr<float>(), wc.stride(0), bias.has_value() ? bc.data_ptr<float>() : nullptr,
+                                            y.data_ptr<float>(), n_out, (int)rows, (int)n_out, (int)k, (int)act, stream);
+    TORCH_CHECK(rc == CMHSA_OK, "gpt2_linear_rows_f32_fwd failed (", rc, "): ", cmhsa_status_string(rc));
+    return y;
+}
+
 // The generation loop's input side (include/gpt2_step.h; reference gpt2.py:43-44): tokens (B, L) int64 (a view of the
 // static token buffer: any row stride), wte (vocab, d), wpe (context, d) -> (B, L, d) = wte[tokens] + wpe[arange(L)].
 at::Tensor embed_tokens(at::Tensor tokens, at::Tensor wte, at::Tensor wpe) {
@@ -252,6 +281,7 @@ TORCH_LIBRARY(causal_multihead_self_attention, m) {
     m.def("causal_multihead_self_attention_decode(Tensor qkv_new, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor pos, int num_heads) -> Tensor");
     m.def("gelu_tanh(Tensor x) -> Tensor");
     m.def("add_layer_norm(Tensor x, Tensor? delta, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor)");
+    m.def("linear_rows(Tensor x, Tensor weight, Tensor? bias, int act) -> Tensor");
     m.def("embed_tokens(Tensor tokens, Tensor wte, Tensor wpe) -> Tensor");
     m.def("greedy_step(Tensor logits, Tensor(a!) done, Tensor(b!) tokens, Tensor pos, int eos) -> ()");
 }
@@ -262,6 +292,7 @@ TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
     m.impl("causal_multihead_self_attention_decode", &causal_multihead_self_attention_decode);
     m.impl("gelu_tanh", &gelu_tanh);
     m.impl("add_layer_norm", &add_layer_norm);
+    m.impl("linear_rows", &linear_rows);
     m.impl("embed_tokens", &embed_tokens);
     m.impl("greedy_step", &greedy_step);
 }

@@ -65,16 +65,19 @@ def test_decode_step_equals_last_row_of_full_attention(gpu_device, B, H):
 
 
 @pytest.mark.gpu
-def test_decode_out_of_range_pos_is_a_no_op_and_strided_caches_work(gpu_device):
+def test_decode_out_of_range_pos_zeroes_the_output_only_and_strided_caches_work(gpu_device):
     torch.manual_seed(8)
     H, d, cap = 12, 768, 64
     new = torch.randn(2, 3 * d, device=gpu_device)
     big = torch.zeros(2, cap, 2 * d, device=gpu_device)                 # K and V interleaved in one buffer: row stride 2*d
     kc, vc = big[..., :d], big[..., d:]
-    out = torch.full((2, d), 3.0, device=gpu_device)
-    for bad in (-1, cap, cap + 5):
+    for bad in (-1, cap, cap + 5):                                      # no key exists: o = 0, the caches are not touched
+        out = torch.full((2, d), 3.0, device=gpu_device)
         cmhsa.decode_step(new, kc, vc, torch.tensor([bad], dtype=torch.int32, device=gpu_device), H, out=out)
-        assert torch.all(out == 3.0) and torch.all(big == 0)
+        assert torch.all(out == 0.0) and torch.all(big == 0)
+        via_op = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_decode(
+            new, kc, vc, torch.tensor([bad], dtype=torch.int32, device=gpu_device), H)
+        assert torch.all(via_op == 0.0) and torch.all(big == 0)
     p = torch.zeros(1, dtype=torch.int32, device=gpu_device)
     seq = torch.randn(2, 40, 3 * d, device=gpu_device)
     full = cmhsa.attention_fwd_packed_qkv(seq, H)

@@ -283,6 +283,15 @@ def test_kv_cache_generation_on_gpu(gpu_device):
     assert gk.generate(prompt) == ref and gk.generate(prompt) == ref
     gk3 = gen.KVCacheGreedyGenerator(every, 3, 128, device=gpu_device)
     assert gk3.generate([prompt] * 3) == [ref[0][:128]] * 3
+    # and with every linear layer of the step through the few-row HIP kernel (bias and GELU inside): fused and plain step
+    gl = gen.KVCacheGreedyGenerator(every, 1, 512, device=gpu_device, few_row_linear=True)
+    assert gl.generate(prompt) == ref and gl.generate(prompt) == ref
+    gl3 = gen.KVCacheGreedyGenerator(every, 3, 128, device=gpu_device, few_row_linear=True)
+    assert gl3.generate([prompt] * 3) == [ref[0][:128]] * 3
+    gp = gen.KVCacheGreedyGenerator(hip, 2, 96, device=gpu_device, few_row_linear=True, use_graphs=False)
+    assert gp.generate([prompt] * 2) == [ref[0][:96]] * 2
+    with pytest.raises(ValueError, match="at most 4 prompts"):
+        gen.KVCacheGreedyGenerator(hip, 5, 32, device=gpu_device, few_row_linear=True)
 
 
 @pytest.mark.gpu
