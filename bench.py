@@ -455,6 +455,25 @@ class Bench:
                             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                          "frac": round(gbs / HBM_PEAK_GBPS, 4), "traffic": None}}
             del kc, vc
+        # the few-row linear layer of the KV-cache step (include/gpt2_linear.h): HBM-bound, the weight matrix read once.
+        # Twelve weight sets in rotation, as a model's layers: nothing is served out of a cache the step would not have.
+        for name, (n_out, kk, sets) in (("linear_rows_gpt2_qkv_1row", (2304, 768, 12)), ("linear_rows_gpt2_lm_head_1row", (50257, 768, 3))):
+            ws = [torch.randn((n_out, kk), device=self.dev) * 0.02 for _ in range(sets)]
+            lb = torch.randn(n_out, device=self.dev)
+            lx = torch.randn((1, kk), device=self.dev)
+            ly = torch.empty((1, n_out), device=self.dev)
+            turn = [0]
+
+            def one_linear():
+                turn[0] = (turn[0] + 1) % sets
+                return lib.gpt2_linear_rows_f32_fwd(lx.data_ptr(), kk, ws[turn[0]].data_ptr(), kk, lb.data_ptr(), ly.data_ptr(), n_out, 1, n_out, kk, 0, sp)
+
+            us = self.events_us(one_linear, reps=60, warm=24)
+            gbs = lib.gpt2_linear_rows_algorithmic_bytes(1, n_out, kk, 1) / us / 1e3
+            others[name] = {"workload": f"few-row linear fp32, 1 row, weight {n_out} x {kk} (+ bias)", "us_per_launch": round(us, 2),
+                            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": round(gbs / HBM_PEAK_GBPS, 4), "traffic": None}}
+            del ws
         return others
 
     # -- generation (the metric's first clause: GPT2 512-token seconds; BASELINE configs 1 and 3) -----------------
