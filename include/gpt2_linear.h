@@ -40,6 +40,24 @@ int gpt2_linear_rows_f32_fwd(const float *x, int64_t x_row_stride, const float *
                              const float *bias, float *y, int64_t y_row_stride,
                              int rows, int n_out, int k, int act, void *stream);
 
+#define GPT2_LN_LINEAR_MAX_ROWS 4
+#define GPT2_LN_LINEAR_MAX_K 4096
+
+/* The same with the residual add and the LayerNorm of the input in front -- the step's QKV layer and first MLP layer,
+ * whose input is `LayerNorm(x + sublayer_out)` (reference transformer_block.py:26-39): ONE launch instead of the
+ * add + LayerNorm launch (include/gpt2_layernorm.h) and the linear launch.
+ *     s[m, :] = x[m, :] + delta[m, :]            (delta == NULL: s = x; sum_out may then be NULL and is not written)
+ *     h[m, :] = ln_weight * (rsqrt(var(s[m, :]) + eps) * (s[m, :] - mean(s[m, :]))) + ln_bias      (torch.nn.LayerNorm)
+ *     y[m, n] = act( sum_k h[m, k] * weight[n, k] + bias[n] )
+ * sum_out (rows x k, contiguous) receives s.  Every wave forms the two statistics of the rows itself (it reads whole rows
+ * of x anyway).  Requirements as above, and: rows <= GPT2_LN_LINEAR_MAX_ROWS, k <= GPT2_LN_LINEAR_MAX_K; delta, ln_weight,
+ * ln_bias, sum_out 16-B aligned; sum_out must not alias x or delta (other waves are still reading them).
+ *                                   [transformer_block.py:26-39 + causal_self_attention.py:224 / transformer_block.py:35] */
+int gpt2_ln_linear_rows_f32_fwd(const float *x, int64_t x_row_stride, const float *delta, int64_t delta_row_stride,
+                                const float *ln_weight, const float *ln_bias, float eps, float *sum_out,
+                                const float *weight, int64_t w_row_stride, const float *bias, float *y, int64_t y_row_stride,
+                                int rows, int n_out, int k, int act, void *stream);
+
 /* Algorithmic HBM bytes of one call: the weight matrix and the bias once, x once, y once. */
 double gpt2_linear_rows_algorithmic_bytes(int rows, int n_out, int k, int with_bias);
 

@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = (
     "gpt2_embed_f32_fwd",            # include/gpt2_step.h
     "gpt2_greedy_step",
     "gpt2_linear_rows_f32_fwd",      # include/gpt2_linear.h
+    "gpt2_ln_linear_rows_f32_fwd",
     "gpt2_linear_rows_algorithmic_bytes",
 )
 
@@ -128,6 +129,8 @@ def load_library() -> ctypes.CDLL:
     lib.gpt2_greedy_step.argtypes = [vp, i64, vp, vp, i64, vp, i32, i32, i32, i64, vp]
     lib.gpt2_linear_rows_f32_fwd.restype = i32
     lib.gpt2_linear_rows_f32_fwd.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.gpt2_ln_linear_rows_f32_fwd.restype = i32
+    lib.gpt2_ln_linear_rows_f32_fwd.argtypes = [vp, i64, vp, i64, vp, vp, ctypes.c_float, vp, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.gpt2_linear_rows_algorithmic_bytes.restype = ctypes.c_double
     lib.gpt2_linear_rows_algorithmic_bytes.argtypes = [i32, i32, i32, i32]
     _lib = lib

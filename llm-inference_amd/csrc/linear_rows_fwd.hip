@@ -135,9 +135,116 @@ hipError_t launch_rows(const LinearParams &p, int rows, hipStream_t s) {
     return hipLaunchKernel(fn, grid, block, args, 0, s);
 }
 
+// ---- the same with the residual add and the LayerNorm of x in front (the step's QKV and first MLP layer):
+//      s = x + delta, h = LayerNorm(s) (torch.nn.LayerNorm arithmetic: biased variance, rsqrt(var + eps),
+//      lnw * (rstd * (s - mean)) + lnb), y = act(h W^T + b).  Every wave reads whole rows of x anyway (lane l the pieces
+//      l, l + 64, ...), so each computes the two statistics itself -- two wave reductions per row -- instead of a
+//      launch of its own in front (4 us for one row of 768: latency, not bytes).  The first workgroup's first wave
+//      stores s for the residual stream.  One pass: k <= 64 lanes * kPieces * 4.
+struct LnLinearParams {
+    LinearParams lin;
+    const float *delta, *lnw, *lnb;
+    float *sum_out;
+    int64_t delta_rs;
+    float eps;
+};
+
+template <int kM, int kPieces>
+__global__ __launch_bounds__(kWavesPerWg * 64) void ln_linear_rows_kernel(LnLinearParams q, int rows) {
+    const LinearParams &p = q.lin;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * kWavesPerWg + wave;
+    if (n >= p.n_out) return;                                    // wave-uniform; the kernel has no barrier
+    const __amdgpu_buffer_rsrc_t wr = row_rsrc(p.w + (uint64_t)(uint32_t)n * (uint64_t)p.w_rs, p.k);
+    f32x4 wv[kPieces];
+#pragma unroll
+    for (int u = 0; u < kPieces; ++u) wv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (u * 64 + lane) * 16, 0, 0));
+    const __amdgpu_buffer_rsrc_t gr = row_rsrc(q.lnw, p.k), br = row_rsrc(q.lnb, p.k);
+    f32x4 g[kPieces], be[kPieces];
+#pragma unroll
+    for (int u = 0; u < kPieces; ++u) {
+        g[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, (u * 64 + lane) * 16, 0, 0));
+        be[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(br, (u * 64 + lane) * 16, 0, 0));
+    }
+    const float b = p.bias ? p.bias[n] : 0.f;
+    const float inv_k = 1.0f / (float)p.k;
+#pragma unroll
+    for (int m = 0; m < kM; ++m) {
+        if (m >= rows) break;                                    // wave-uniform
+        const __amdgpu_buffer_rsrc_t xr = row_rsrc(p.x + (uint64_t)(uint32_t)m * (uint64_t)p.x_rs, p.k);
+        const __amdgpu_buffer_rsrc_t dr = row_rsrc(q.delta ? q.delta + (uint64_t)(uint32_t)m * (uint64_t)q.delta_rs : p.x, q.delta ? p.k : 0);
+        f32x4 sv[kPieces];
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < kPieces; ++u) {
+            const f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (u * 64 + lane) * 16, 0, 0));
+            const f32x4 dv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, (u * 64 + lane) * 16, 0, 0));
+            sv[u] = xv + dv;                                     // pieces past the end of the row: 0 + 0
+            sum += (sv[u].x + sv[u].y) + (sv[u].z + sv[u].w);
+        }
+        const float mean = wave_sum(sum) * inv_k;
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < kPieces; ++u) {
+            const bool in_row = (u * 64 + lane) * 4 < p.k;
+            const f32x4 c = sv[u] - mean;
+            sq += in_row ? (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w) : 0.f;
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * inv_k + q.eps);
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < kPieces; ++u) {
+            const f32x4 h = g[u] * (rstd * (sv[u] - mean)) + be[u];            // 0 * (..) + 0 past the end of the row
+            acc = __builtin_fmaf(wv[u].w, h.w, __builtin_fmaf(wv[u].z, h.z, __builtin_fmaf(wv[u].y, h.y, __builtin_fmaf(wv[u].x, h.x, acc))));
+        }
+        if (q.sum_out && blockIdx.x == 0 && wave == 0) {
+            const __amdgpu_buffer_rsrc_t sr = row_rsrc(q.sum_out + (uint64_t)(uint32_t)m * (uint64_t)p.k, p.k);
+#pragma unroll
+            for (int u = 0; u < kPieces; ++u)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[u]), sr, (u * 64 + lane) * 16, 0, 0);   // out of range: dropped
+        }
+        float r = wave_sum(acc) + b;
+        if (p.act == GPT2_LINEAR_ACT_GELU_TANH) r = gelu_one(r);
+        if (lane == 0) p.y[(int64_t)m * p.y_rs + n] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int gpt2_ln_linear_rows_f32_fwd(const float *x, int64_t x_row_stride, const float *delta, int64_t delta_row_stride,
+                                const float *ln_weight, const float *ln_bias, float eps, float *sum_out,
+                                const float *weight, int64_t w_row_stride, const float *bias, float *y, int64_t y_row_stride,
+                                int rows, int n_out, int k, int act, void *stream) {
+    if (rows < 0 || n_out < 0 || k <= 0 || (k & 3) || rows > GPT2_LN_LINEAR_MAX_ROWS || k > GPT2_LN_LINEAR_MAX_K) return CMHSA_ERR_BAD_SHAPE;
+    if (act != GPT2_LINEAR_ACT_NONE && act != GPT2_LINEAR_ACT_GELU_TANH) return CMHSA_ERR_BAD_SHAPE;
+    if (x_row_stride < 0 || delta_row_stride < 0 || w_row_stride < 0 || y_row_stride < 0) return CMHSA_ERR_BAD_SHAPE;
+    if (rows == 0 || n_out == 0) return CMHSA_OK;
+    if (!x || !ln_weight || !ln_bias || !weight || !y || (delta && !sum_out)) return CMHSA_ERR_NULL_POINTER;
+    if ((((uintptr_t)x | (uintptr_t)delta | (uintptr_t)ln_weight | (uintptr_t)ln_bias | (uintptr_t)sum_out | (uintptr_t)weight) & 15) ||
+        ((x_row_stride | delta_row_stride | w_row_stride) & 3) || (((uintptr_t)y | (uintptr_t)bias) & 3))
+        return CMHSA_ERR_ALIGNMENT;
+    if (rows > 1 && (x_row_stride < k || (delta && delta_row_stride < k) || y_row_stride < n_out)) return CMHSA_ERR_BAD_SHAPE;
+    if (w_row_stride < k && n_out > 1) return CMHSA_ERR_BAD_SHAPE;
+    LnLinearParams q;
+    q.lin.x = x; q.lin.w = weight; q.lin.bias = bias; q.lin.y = y;
+    q.lin.x_rs = x_row_stride; q.lin.w_rs = w_row_stride; q.lin.y_rs = y_row_stride;
+    q.lin.n_out = n_out; q.lin.k = k; q.lin.act = act;
+    q.delta = delta; q.delta_rs = delta_row_stride; q.lnw = ln_weight; q.lnb = ln_bias; q.sum_out = sum_out; q.eps = eps;
+    const int per_lane = (k / 4 + 63) / 64;
+    const void *fn = nullptr;
+    if (per_lane <= 4) fn = rows == 1 ? reinterpret_cast<const void *>(ln_linear_rows_kernel<1, 4>) : rows == 2 ? reinterpret_cast<const void *>(ln_linear_rows_kernel<2, 4>)
+                                                                                                              : reinterpret_cast<const void *>(ln_linear_rows_kernel<4, 4>);
+    else if (per_lane <= 8) fn = rows == 1 ? reinterpret_cast<const void *>(ln_linear_rows_kernel<1, 8>) : rows == 2 ? reinterpret_cast<const void *>(ln_linear_rows_kernel<2, 8>)
+                                                                                                                   : reinterpret_cast<const void *>(ln_linear_rows_kernel<4, 8>);
+    else fn = rows == 1 ? reinterpret_cast<const void *>(ln_linear_rows_kernel<1, 16>) : rows == 2 ? reinterpret_cast<const void *>(ln_linear_rows_kernel<2, 16>)
+                                                                                                 : reinterpret_cast<const void *>(ln_linear_rows_kernel<4, 16>);
+    const dim3 grid((unsigned)((n_out + kWavesPerWg - 1) / kWavesPerWg)), block(kWavesPerWg * 64);
+    void *args[] = {&q, &rows};
+    const hipError_t e = hipLaunchKernel(fn, grid, block, args, 0, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? CMHSA_OK : (int)e;
+}
 
 double gpt2_linear_rows_algorithmic_bytes(int rows, int n_out, int k, int with_bias) {
     return 4.0 * ((double)n_out * k + (with_bias ? n_out : 0) + (double)rows * k + (double)rows * n_out);

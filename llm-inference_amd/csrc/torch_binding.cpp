@@ -237,6 +237,45 @@ at::Tensor linear_rows(at::Tensor x, at::Tensor weight, const c10::optional<at::
     return y;
 }
 
+// The same with the residual add and the LayerNorm of the input in front (include/gpt2_linear.h): returns
+// (x + delta, act(LayerNorm(x + delta) W^T + b)); without delta the first is x itself.  At most 4 rows of x.
+std::tuple<at::Tensor, at::Tensor> ln_linear_rows(at::Tensor x, const c10::optional<at::Tensor> &delta, at::Tensor ln_weight, at::Tensor ln_bias,
+                                                  double eps, at::Tensor weight, const c10::optional<at::Tensor> &bias, int64_t act) {
+    for (const at::Tensor *t : {&x, &ln_weight, &ln_bias, &weight})
+        TORCH_CHECK(t->is_cuda() && t->dtype() == at::kFloat && t->device() == x.device(), "tensors must be float32 CUDA tensors on one device");
+    TORCH_CHECK(x.dim() >= 1 && weight.dim() == 2 && x.size(-1) == weight.size(1), "x must be (..., k) and weight (n_out, k)");
+    const int64_t k = weight.size(1), n_out = weight.size(0);
+    TORCH_CHECK(ln_weight.numel() == k && ln_bias.numel() == k, "ln_weight and ln_bias must have k elements");
+    const at::Tensor xc = x.contiguous(), wc = weight.stride(1) == 1 ? weight : weight.contiguous(), gc = ln_weight.contiguous(), bec = ln_bias.contiguous();
+    const int64_t rows = k ? xc.numel() / k : 0;
+    TORCH_CHECK(rows <= GPT2_LN_LINEAR_MAX_ROWS && k <= GPT2_LN_LINEAR_MAX_K, "ln_linear_rows is for at most ", GPT2_LN_LINEAR_MAX_ROWS, " rows of at most ", GPT2_LN_LINEAR_MAX_K, " floats");
+    at::Tensor dc, bc;
+    if (delta.has_value()) {
+        TORCH_CHECK(delta->is_cuda() && delta->dtype() == at::kFloat && delta->sizes() == x.sizes() && delta->device() == x.device(),
+                    "delta must be a float32 CUDA tensor of x's shape on x's device");
+        dc = delta->contiguous();
+    }
+    if (bias.has_value()) {
+        TORCH_CHECK(bias->is_cuda() && bias->dtype() == at::kFloat && bias->numel() == n_out && bias->device() == x.device(),
+                    "bias must be a float32 CUDA tensor with n_out elements on x's device");
+        bc = bias->contiguous();
+    }
+    std::vector<int64_t> out_sizes(x.sizes().begin(), x.sizes().end());
+    out_sizes.back() = n_out;
+    at::Tensor y = at::empty(out_sizes, x.options().memory_format(c10::MemoryFormat::Contiguous));
+    at::Tensor sum = delta.has_value() ? at::empty_like(xc) : xc;
+    if (y.numel() == 0 || xc.numel() == 0) return {sum, y};
+    TORCH_CHECK(n_out <= INT32_MAX, "shape exceeds 32-bit indexing");
+    const c10::hip::HIPGuard guard(x.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(x.device().index()).stream();
+    const int rc = gpt2_ln_linear_rows_f32_fwd(xc.data_ptr<float>(), k, delta.has_value() ? dc.data_ptr<float>() : nullptr, k, gc.data_ptr<float>(),
+                                               bec.data_ptr<float>(), (float)eps, delta.has_value() ? sum.data_ptr<float>() : nullptr, wc.data_ptr<float>(),
+                                               wc.stride(0), bias.has_value() ? bc.data_ptr<float>() : nullptr, y.data_ptr<float>(), n_out,
+                                               (int)rows, (int)n_out, (int)k, (int)act, stream);
+    TORCH_CHECK(rc == CMHSA_OK, "gpt2_ln_linear_rows_f32_fwd failed (", rc, "): ", cmhsa_status_string(rc));
+    return {sum, y};
+}
+
 // The generation loop's input side (include/gpt2_step.h; reference gpt2.py:43-44): tokens (B, L) int64 (a view of the
 // static token buffer: any row stride), wte (vocab, d), wpe (context, d) -> (B, L, d) = wte[tokens] + wpe[arange(L)].
 at::Tensor embed_tokens(at::Tensor tokens, at::Tensor wte, at::Tensor wpe) {
@@ -282,6 +321,7 @@ TORCH_LIBRARY(causal_multihead_self_attention, m) {
     m.def("gelu_tanh(Tensor x) -> Tensor");
     m.def("add_layer_norm(Tensor x, Tensor? delta, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor)");
     m.def("linear_rows(Tensor x, Tensor weight, Tensor? bias, int act) -> Tensor");
+    m.def("ln_linear_rows(Tensor x, Tensor? delta, Tensor ln_weight, Tensor ln_bias, float eps, Tensor weight, Tensor? bias, int act) -> (Tensor, Tensor)");
     m.def("embed_tokens(Tensor tokens, Tensor wte, Tensor wpe) -> Tensor");
     m.def("greedy_step(Tensor logits, Tensor(a!) done, Tensor(b!) tokens, Tensor pos, int eos) -> ()");
 }
@@ -293,6 +333,7 @@ TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
     m.impl("gelu_tanh", &gelu_tanh);
     m.impl("add_layer_norm", &add_layer_norm);
     m.impl("linear_rows", &linear_rows);
+    m.impl("ln_linear_rows", &ln_linear_rows);
     m.impl("embed_tokens", &embed_tokens);
     m.impl("greedy_step", &greedy_step);
 }

@@ -425,6 +425,9 @@ class KVCacheGreedyGenerator:
     def _linear(self, layer: nn.Linear, x: torch.Tensor, gelu: bool = False) -> torch.Tensor:
         return torch.ops.causal_multihead_self_attention.linear_rows(x, layer.weight, layer.bias, 1 if gelu else 0)
 
+    def _ln_linear(self, x, delta, ln: nn.LayerNorm, layer: nn.Linear, gelu: bool = False):
+        return torch.ops.causal_multihead_self_attention.ln_linear_rows(x, delta, ln.weight, ln.bias, ln.eps, layer.weight, layer.bias, 1 if gelu else 0)
+
     @torch.no_grad()
     def _step_fused(self) -> None:
         """The same step with the model's opt-in fusions: every residual add inside the LayerNorm behind it
@@ -435,13 +438,14 @@ class KVCacheGreedyGenerator:
         delta = None
         for i, blk in enumerate(m.blocks):
             a = blk.attention
-            x, h = fused_add_layer_norm(x, delta, blk.first_layer_norm)
             if self.few_row_linear:
-                qkv = self._linear(a.qkv_layer, h)
+                # residual add + LayerNorm inside the linear kernel behind it: five launches per layer
+                x, qkv = self._ln_linear(x, delta, blk.first_layer_norm, a.qkv_layer)
                 ctx = self.decode_fn(qkv[:, 0, :], self.k_cache[i], self.v_cache[i], self.pos32, a.num_heads)
-                x, h = fused_add_layer_norm(x, self._linear(a.out_proj_layer, ctx).unsqueeze(1), blk.second_layer_norm)
-                delta = self._linear(blk.mlp_out, self._linear(blk.mlp_in, h, gelu=True))
+                x, up = self._ln_linear(x, self._linear(a.out_proj_layer, ctx).unsqueeze(1), blk.second_layer_norm, blk.mlp_in, gelu=True)
+                delta = self._linear(blk.mlp_out, up)
                 continue
+            x, h = fused_add_layer_norm(x, delta, blk.first_layer_norm)
             qkv = a.qkv_layer(h)
             ctx = self.decode_fn(qkv[:, 0, :], self.k_cache[i], self.v_cache[i], self.pos32, a.num_heads)
             x, h = fused_add_layer_norm(x, a.out_proj_layer(ctx).unsqueeze(1), blk.second_layer_norm)

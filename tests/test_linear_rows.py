@@ -109,3 +109,78 @@ def test_strided_weight_rows_and_torch_op(gpu_device):
     all8 = op(xs, w, b, 0)
     for r in (1, 2, 4, 5):
         assert torch.equal(op(xs[:r], w, b, 0), all8[:r])
+
+
+def test_ln_linear_argument_checks_without_a_gpu():
+    f = cmhsa.load_library().gpt2_ln_linear_rows_f32_fwd
+    p = ctypes.c_void_p(4096)
+    ok = (p, 768, p, 768, p, p, 1e-5, p, p, 768, p, p, 2304)
+    assert f(*ok, 0, 2304, 768, 0, None) == cmhsa.CMHSA_OK                                           # no rows: no-op
+    assert f(*ok, 5, 2304, 768, 0, None) == cmhsa.CMHSA_ERR_BAD_SHAPE                                # more than 4 rows
+    assert f(p, 8192, p, 8192, p, p, 1e-5, p, p, 8192, p, p, 2304, 1, 2304, 8192, 0, None) == cmhsa.CMHSA_ERR_BAD_SHAPE   # k > 4096
+    assert f(*ok, 1, 2304, 770, 0, None) == cmhsa.CMHSA_ERR_BAD_SHAPE                                # k % 4
+    assert f(*ok, 1, 2304, 768, 3, None) == cmhsa.CMHSA_ERR_BAD_SHAPE                                # unknown activation
+    assert f(p, 768, p, 768, p, p, 1e-5, None, p, 768, p, p, 2304, 1, 2304, 768, 0, None) == cmhsa.CMHSA_ERR_NULL_POINTER   # delta without sum_out
+    assert f(p, 768, None, 0, p, p, 1e-5, None, p, 768, p, p, 2304, 1, 2304, 768, 0, None) != cmhsa.CMHSA_ERR_NULL_POINTER  # no delta: sum_out optional
+    assert f(p, 768, p, 768, None, p, 1e-5, p, p, 768, p, p, 2304, 1, 2304, 768, 0, None) == cmhsa.CMHSA_ERR_NULL_POINTER
+    assert f(p, 768, ctypes.c_void_p(4100), 768, p, p, 1e-5, p, p, 768, p, p, 2304, 1, 2304, 768, 0, None) == cmhsa.CMHSA_ERR_ALIGNMENT
+    assert f(p, 764, p, 768, p, p, 1e-5, p, p, 768, p, p, 2304, 2, 2304, 768, 0, None) == cmhsa.CMHSA_ERR_BAD_SHAPE          # rows of x overlap
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_out,k", [(2304, 768), (3072, 768), (3072, 1024), (3840, 1280), (4800, 1600), (6400, 1600), (50, 4), (9, 260), (130, 4096)])
+@pytest.mark.parametrize("rows", [1, 2, 3, 4])
+def test_ln_linear_against_oracles_through_c_abi(n_out, k, rows, gpu_device):
+    """s = x + delta; h = LayerNorm(s); y = act(h W^T + b): s bit-equal to the fp32 add, y against the LayerNorm oracle
+    (oracle/layernorm.py) followed by the linear oracle (oracle/linear.py), both in float64."""
+    from oracle import layernorm as ln_oracle
+
+    rng = np.random.default_rng(n_out + 31 * k + rows)
+    x = (rng.standard_normal((rows, k), dtype=np.float32) * 2 + 0.5).astype(np.float32)
+    delta = rng.standard_normal((rows, k), dtype=np.float32)
+    g = rng.standard_normal(k, dtype=np.float32)
+    be = rng.standard_normal(k, dtype=np.float32)
+    w = (rng.standard_normal((n_out, k), dtype=np.float32) * 0.05).astype(np.float32)
+    b = rng.standard_normal(n_out, dtype=np.float32)
+    tx, td, tg, tbe, tw, tb = (torch.from_numpy(a).to(gpu_device) for a in (x, delta, g, be, w, b))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+    f = cmhsa.load_library().gpt2_ln_linear_rows_f32_fwd
+    for act in (0, 1):
+        for with_delta in (True, False):
+            s_out = torch.full((rows, k), float("nan"), device=gpu_device)
+            y = torch.full((rows, n_out), float("nan"), device=gpu_device)
+            rc = f(tx.data_ptr(), k, td.data_ptr() if with_delta else None, k, tg.data_ptr(), tbe.data_ptr(), 1e-5,
+                   s_out.data_ptr() if with_delta else None, tw.data_ptr(), k, tb.data_ptr(), y.data_ptr(), n_out, rows, n_out, k, act, stream)
+            assert rc == 0
+            s_want, h = ln_oracle.add_layer_norm_f64(x, delta if with_delta else None, g, be)
+            if with_delta:
+                assert np.array_equal(s_out.cpu().numpy(), s_want)
+            else:
+                assert torch.isnan(s_out).all()                                            # not written without delta
+            lin = oracle.linear_f64(h, w, b)
+            want = gelu_oracle.gelu_tanh_f64(lin) if act else lin
+            # h carries fp32 LayerNorm rounding (a few ulp of |h| <= ~10) into a sum of k terms
+            scale = oracle.sum_scale(np.abs(h) + 1e-3, w, b)
+            assert (np.abs(y.cpu().numpy() - want) <= 4e-6 * scale + 1e-6).all(), (act, with_delta)
+
+
+@pytest.mark.gpu
+def test_ln_linear_torch_op_equals_the_two_launch_form_closely(gpu_device):
+    import causal_multihead_self_attention  # noqa: F401
+
+    ops = torch.ops.causal_multihead_self_attention
+    torch.manual_seed(5)
+    x, delta = torch.randn(2, 1, 768, device=gpu_device), torch.randn(2, 1, 768, device=gpu_device)
+    ln = torch.nn.LayerNorm(768).to(gpu_device)
+    with torch.no_grad():
+        ln.weight.normal_(); ln.bias.normal_()
+    lin = torch.nn.Linear(768, 3072).to(gpu_device)
+    s, y = ops.ln_linear_rows(x, delta, ln.weight, ln.bias, ln.eps, lin.weight, lin.bias, 1)
+    s2, h2 = ops.add_layer_norm(x, delta, ln.weight, ln.bias, ln.eps)
+    y2 = ops.linear_rows(h2, lin.weight, lin.bias, 1)
+    assert s.shape == x.shape and y.shape == (2, 1, 3072) and torch.equal(s, s2)
+    assert (y - y2).abs().max().item() <= 2e-5
+    s0, y0 = ops.ln_linear_rows(x, None, ln.weight, ln.bias, ln.eps, lin.weight, None, 0)
+    assert s0.data_ptr() == x.data_ptr() or torch.equal(s0, x)
+    with pytest.raises(RuntimeError, match="at most 4 rows"):
+        ops.ln_linear_rows(torch.randn(5, 768, device=gpu_device), None, ln.weight, ln.bias, ln.eps, lin.weight, None, 0)
