@@ -108,10 +108,80 @@ __global__ __launch_bounds__(kWavesPerWg * 64) void linear_rows_kernel(LinearPar
     }
 }
 
+// Few output columns, long rows (the second MLP layer: 768 x 3072, 1600 x 6400): one wave per column leaves most of the
+// chip without a wave and each wave with a long row.  Here kSplit waves of a workgroup share a column, each a contiguous
+// slice of k (slice_pieces 16-B pieces, a multiple of 64); the kSplit partial sums meet in LDS and are added in slice order.
+template <int kM, int kPieces, int kSplit>
+__global__ __launch_bounds__(kWavesPerWg * 64) void linear_rows_split_kernel(LinearParams p, int rows, int slice_pieces) {
+    __shared__ float part[kWavesPerWg][kM];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slice = wave % kSplit;
+    const int n = blockIdx.x * (kWavesPerWg / kSplit) + wave / kSplit;
+    const bool live = n < p.n_out;                               // a dead wave loads nothing (zero-byte descriptors) but meets the barrier
+    const int k0 = slice * slice_pieces * 4;
+    const int klen = live ? max(0, min(p.k - k0, slice_pieces * 4)) : 0;
+    const __amdgpu_buffer_rsrc_t wr = row_rsrc(p.w + (uint64_t)(uint32_t)min(n, p.n_out - 1) * (uint64_t)p.w_rs + k0, klen);
+    __amdgpu_buffer_rsrc_t xr[kM];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) xr[m] = row_rsrc(p.x + (uint64_t)(uint32_t)min(m, rows - 1) * (uint64_t)p.x_rs + k0, m < rows ? klen : 0);
+    float acc[kM];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) acc[m] = 0.f;
+    for (int piece0 = 0; piece0 < slice_pieces; piece0 += 64 * kPieces) {
+        f32x4 wv[kPieces];
+#pragma unroll
+        for (int u = 0; u < kPieces; ++u)
+            wv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (piece0 + u * 64 + lane) * 16, 0, 0));
+#pragma unroll
+        for (int u = 0; u < kPieces; ++u) {
+#pragma unroll
+            for (int m = 0; m < kM; ++m) {
+                const f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr[m], (piece0 + u * 64 + lane) * 16, 0, 0));
+                acc[m] = __builtin_fmaf(wv[u].w, xv.w, __builtin_fmaf(wv[u].z, xv.z, __builtin_fmaf(wv[u].y, xv.y, __builtin_fmaf(wv[u].x, xv.x, acc[m]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kM; ++m) {
+        const float t = wave_sum(acc[m]);
+        if (lane == 0) part[wave][m] = t;
+    }
+    __syncthreads();
+    if (slice == 0 && live && lane == 0) {
+        const float b = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int m = 0; m < kM; ++m) {
+            float t = part[wave][m];
+#pragma unroll
+            for (int j = 1; j < kSplit; ++j) t += part[wave + j][m];
+            t += b;
+            if (p.act == GPT2_LINEAR_ACT_GELU_TANH) t = gelu_one(t);
+            if (m < rows) p.y[(int64_t)m * p.y_rs + n] = t;
+        }
+    }
+}
+
+template <int kM, int kSplit>
+hipError_t launch_split(const LinearParams &p, int rows, hipStream_t s) {
+    int slice_pieces = ((p.k / 4 + kSplit - 1) / kSplit + 63) / 64 * 64;
+    const int per_lane = slice_pieces / 64;
+    const void *fn = per_lane <= 4 ? reinterpret_cast<const void *>(linear_rows_split_kernel<kM, 4, kSplit>)
+                     : (per_lane <= 8 || kM > 2) ? reinterpret_cast<const void *>(linear_rows_split_kernel<kM, 8, kSplit>)
+                                                 : reinterpret_cast<const void *>(linear_rows_split_kernel<kM, 16, kSplit>);
+    const int per_wg = kWavesPerWg / kSplit;
+    const dim3 grid((unsigned)((p.n_out + per_wg - 1) / per_wg)), block(kWavesPerWg * 64);
+    LinearParams pp = p;
+    void *args[] = {&pp, &rows, &slice_pieces};
+    return hipLaunchKernel(fn, grid, block, args, 0, s);
+}
+
 template <int kM>
 hipError_t launch_rows(const LinearParams &p, int rows, hipStream_t s) {
     // pieces per lane per pass: the whole row in one pass up to k = 4096 (one and two rows of x), 2048 beyond two rows
     const int per_lane = (p.k / 4 + 63) / 64;
+    // waves per column: a function of the layer's shape ONLY (a row of x must give the same bits whatever the rows beside it)
+    if (p.n_out < 1024 && per_lane >= 8) return launch_split<kM, 4>(p, rows, s);
+    if (p.n_out < 2048 && per_lane >= 4) return launch_split<kM, 2>(p, rows, s);
     const int pieces = per_lane <= 4 ? 4 : (per_lane <= 8 || kM > 2) ? 8 : 16;
     // columns per wave: one for a single row of x (the weights are all there is to fetch: as many waves as possible);
     // otherwise up to 16 weight pieces per lane in flight, as long as ~1024 waves remain
