@@ -57,28 +57,56 @@ def _kernel_sources() -> tuple[list[str], list[str]]:
     return hip, headers
 
 
-def build_kernel_lib(force: bool = False) -> str:
+OBJDIR = os.path.join(HERE, "build")              # git-ignored; objects only, the libraries live where they are loaded from
+
+
+def _compile_objects(jobs: list[tuple[str, str, list[str]]]) -> None:
+    """(source, object, extra flags) -> hipcc -c, all at once: the files are independent and the few-row linear kernels
+    alone take a minute (dozens of template instantiations)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(OBJDIR, exist_ok=True)
+    cmds = [[HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", *flags, "-I" + INCLUDE, "-o", obj, src] for src, obj, flags in jobs]
+    if not cmds:
+        return
+    with ThreadPoolExecutor(max_workers=min(len(cmds), max(1, min(8, os.cpu_count() or 1)))) as pool:
+        list(pool.map(_run, cmds))
+
+
+def _obj(src: str, tag: str = "") -> str:
+    return os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + tag + ".o")
+
+
+def build_kernel_lib(force: bool = False, with_test_build: bool = False) -> str:
+    """libcmhsa_hip.so, and with_test_build also tests/helpers/libcmhsa_hip_planenv.so: the same objects except cmhsa_fwd,
+    which is compiled a second time with -DCMHSA_PLAN_ENV (the only file that reads the macro)."""
     hip, headers = _kernel_sources()
-    if force or _stale(KERNEL_LIB, hip + headers):
+    jobs = [(src, _obj(src), []) for src in hip if force or _stale(_obj(src), [src] + headers)]
+    fwd = hip[0]
+    if with_test_build and (force or _stale(_obj(fwd, "_planenv"), [fwd] + headers)):
+        jobs.append((fwd, _obj(fwd, "_planenv"), ["-DCMHSA_PLAN_ENV"]))
+    _compile_objects(jobs)
+    objs = [_obj(src) for src in hip]
+    if force or _stale(KERNEL_LIB, objs):
         os.makedirs(LIBDIR, exist_ok=True)
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-I" + INCLUDE, "-o", KERNEL_LIB, *hip])
+        _run([HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", KERNEL_LIB, *objs])
+    if with_test_build:
+        test_objs = [_obj(fwd, "_planenv")] + objs[1:]
+        if force or _stale(PLANENV_LIB, test_objs):
+            _run([HIPCC, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", PLANENV_LIB, *test_objs])
     return KERNEL_LIB
 
 
 def build_test_libs(force: bool = False) -> None:
     """Test-only libraries (never loaded by the product package): the plan-forcing build and the helper kernels."""
-    hip, headers = _kernel_sources()
-    if force or _stale(PLANENV_LIB, hip + headers):
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCMHSA_PLAN_ENV",
-              "-I" + INCLUDE, "-o", PLANENV_LIB, *hip])
+    build_kernel_lib(force, with_test_build=True)
     helper_src = [os.path.join(TEST_HELPERS, "lds_poison.hip")]
     if force or _stale(TESTHELPER_LIB, helper_src):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", TESTHELPER_LIB, *helper_src])
 
 
 def build_torch_binding(force: bool = False) -> str:
-    srcs = [os.path.join(CSRC, "torch_binding.cpp"), os.path.join(INCLUDE, "cmhsa.h"), os.path.join(INCLUDE, "gpt2_gelu.h"), KERNEL_LIB]
+    srcs = [os.path.join(CSRC, "torch_binding.cpp"), *(os.path.join(INCLUDE, h) for h in ("cmhsa.h", "gpt2_gelu.h", "gpt2_layernorm.h", "gpt2_step.h", "gpt2_linear.h")), KERNEL_LIB]
     if force or _stale(EXT_PATH, srcs):
         import torch
         from torch.utils import cpp_extension
@@ -96,9 +124,9 @@ def build_torch_binding(force: bool = False) -> str:
 
 
 def build_all(force: bool = False) -> None:
-    build_kernel_lib(force)
+    build_kernel_lib(force, with_test_build=True)      # every object in one parallel batch
     build_torch_binding(force)
-    build_test_libs(force)
+    build_test_libs(False)
 
 
 if __name__ == "__main__":
