@@ -51,9 +51,9 @@ def _run(cmd: list[str]) -> None:
 
 
 def _kernel_sources() -> tuple[list[str], list[str]]:
-    hip = [os.path.join(CSRC, "cmhsa_fwd.hip"), os.path.join(CSRC, "cmhsa_decode.hip"), os.path.join(CSRC, "gelu_fwd.hip"), os.path.join(CSRC, "add_layernorm_fwd.hip"), os.path.join(CSRC, "gpt2_step.hip"), os.path.join(CSRC, "linear_rows_fwd.hip")]
+    hip = [os.path.join(CSRC, "cmhsa_fwd.hip"), os.path.join(CSRC, "cmhsa_fwd16.hip"), os.path.join(CSRC, "cmhsa_decode.hip"), os.path.join(CSRC, "gelu_fwd.hip"), os.path.join(CSRC, "add_layernorm_fwd.hip"), os.path.join(CSRC, "gpt2_step.hip"), os.path.join(CSRC, "linear_rows_fwd.hip")]
     headers = [os.path.join(INCLUDE, "cmhsa.h"), os.path.join(INCLUDE, "gpt2_gelu.h"), os.path.join(INCLUDE, "gpt2_layernorm.h"), os.path.join(INCLUDE, "gpt2_step.h"), os.path.join(INCLUDE, "gpt2_linear.h"), os.path.join(CSRC, "gelu_one.h"),
-               os.path.join(CSRC, "cmhsa_common.h"), os.path.join(CSRC, "cmhsa_plan.h")]
+               os.path.join(CSRC, "cmhsa_common.h"), os.path.join(CSRC, "cmhsa_plan.h"), os.path.join(CSRC, "cmhsa_tiles16.h")]
     return hip, headers
 
 

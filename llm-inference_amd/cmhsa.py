@@ -160,6 +160,19 @@ def plan_dump(batch: int, seq_len: int, num_heads: int, with_workspace: bool = F
     names = ("waves", "segs", "wgs_per_bh", "grid_x", "grid_y", "grid_z", "parts_per_bh", "splits_per_bh", "simd_cap", "nqb",
              "use_table", "longest_first", "chain", "n_paired", "n_alone", "workspace_256")
     plan = dict(zip(names, buf[:16]))
+    if plan["use_table"] == 2:
+        # the 16-row-block family (csrc/cmhsa_tiles16.h): "segs" = job words per wave, "nqb" = 16-row blocks per (b,h),
+        # "simd_cap" = tiles on the longest wave; per workgroup four waves, per wave its jobs as
+        # (block, first_tile, tiles, rank, pieces); "merges" = per workgroup, the barrier flag of each wave's first word
+        J = plan["segs"]
+        plan.update(family="tiles16", jobs_per_wave=J, n16=plan["nqb"], tiles_per_wave=plan["simd_cap"])
+        words = [[[buf[16 + (j * 4 + w) * J + i] & 0xffffffff for i in range(J)] for w in range(4)] for j in range(plan["wgs_per_bh"])]
+        plan["workgroups"] = [[[(x & 255, (x >> 8) & 255, (x >> 16) & 255, (x >> 24) & 3, (x >> 26) & 7) for x in wave if (x >> 16) & 255]
+                               for wave in wg] for wg in words]
+        plan["merges"] = [[bool(wave[0] >> 31) for wave in wg] for wg in words]
+        plan["raw_words"] = words
+        return plan
+    plan["family"] = "units32"
     segs = plan["segs"]
     plan["workgroups"] = [[tuple(buf[16 + (j * segs + i) * 5: 16 + (j * segs + i) * 5 + 5]) for i in range(segs)
                            if buf[16 + (j * segs + i) * 5] != 0] for j in range(plan["wgs_per_bh"])]

@@ -786,10 +786,13 @@ int cmhsa_version(void) { return (1 << 16) | 0; }
 int cmhsa_debug_set_stamps(unsigned long long *buf, int block) {
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_block), &block, sizeof(block));
+    if (e == hipSuccess) e = (hipError_t)cmhsa_t16::debug_set_stamps(buf, block);
     return (int)e;
 }
 int cmhsa_debug_set_block_times(unsigned long long *buf) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_block_times), &buf, sizeof(buf));
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_block_times), &buf, sizeof(buf));
+    if (e == hipSuccess) e = (hipError_t)cmhsa_t16::debug_set_block_times(buf);
+    return (int)e;
 }
 #endif
 
@@ -844,10 +847,15 @@ int forward(const float *q, const float *k, const float *v, float *o,
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
     const int cus = device_cu_count(dev);
-    Plan plan = cached_plan(bh, (int)nqb, cus, workspace != nullptr);
+    Plan plan = cached_plan(bh, seq_len, cus, workspace != nullptr);
     if (plan_workspace_bytes(plan, bh) > workspace_bytes) {
         if (reject_short_workspace) return CMHSA_ERR_WORKSPACE;
-        plan = cached_plan(bh, (int)nqb, cus, false);             // a short workspace selects the plan that needs none
+        plan = cached_plan(bh, seq_len, cus, false);              // a short workspace selects the plan that needs none
+    }
+    if (plan.tiles16) {                                           // the 16-row-block family: its own kernel and arguments (cmhsa_fwd16.hip)
+        const int e16 = cmhsa_t16::launch(plan.t16, q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride,
+                                          q_batch_stride, k_batch_stride, v_batch_stride, o_batch_stride, bh, seq_len, num_heads, stream);
+        return e16 == (int)hipSuccess ? CMHSA_OK : e16;
     }
     const PackPlan &pl = plan.pp;
     const int waves = pl.waves;
@@ -936,7 +944,7 @@ size_t cmhsa_fp32_fwd_workspace_bytes(int batch, int seq_len, int num_heads) {
     if ((nqb + 16) * kKeyUnit > 0x7fffffffLL || bh > 0x7fffffffLL) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-    return plan_workspace_bytes(cached_plan(bh, (int)nqb, device_cu_count(dev), true), bh);
+    return plan_workspace_bytes(cached_plan(bh, seq_len, device_cu_count(dev), true), bh);
 }
 
 int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspace, char *buf, int buf_len) {
@@ -948,7 +956,13 @@ int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspac
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
     const int cus = device_cu_count(dev);
-    const Plan pl = cached_plan(bh, (int)nqb, cus, with_workspace != 0);
+    const Plan pl = cached_plan(bh, seq_len, cus, with_workspace != 0);
+    if (pl.tiles16) {
+        snprintf(buf, (size_t)buf_len, "%s: 4-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, %d 16-row blocks per (b,h), at most %d tiles "
+                 "and %d jobs per wave, workspace 0 B, estimate %.0f cycles", pl.family, pl.t16.wgs_per_bh, (long long)bh, cus, pl.t16.n16,
+                 pl.t16.tiles_per_wave, pl.t16.max_jobs, pl.cycles);
+        return CMHSA_OK;
+    }
     snprintf(buf, (size_t)buf_len, "%s: %d-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, chain cap %d, SIMD cap %d, "
              "%d of %lld query blocks per (b,h) split across workgroups, workspace %zu B, estimate %.0f cycles",
              pl.family, pl.pp.waves, pl.pp.wgs_per_bh, (long long)bh, cus, pl.pp.chain, pl.simd_cap, pl.splits_per_bh,
@@ -965,7 +979,19 @@ int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, i
         if (hipGetDevice(&dev) != hipSuccess) dev = -1;
         cus = device_cu_count(dev);
     }
-    const Plan plan = cached_plan(bh, (int)nqb, cus, with_workspace != 0);
+    const Plan plan = cached_plan(bh, seq_len, cus, with_workspace != 0);
+    if (plan.tiles16) {
+        // the 16-row-block family: header as below with out[1] = job words per wave, out[10] = 2, out[9] = 16-row blocks;
+        // then, per workgroup of a (b,h) and per wave, its job words as they are (cmhsa_tiles16.h)
+        const cmhsa_t16::Plan16 &t = plan.t16;
+        const int64_t total = bh * t.wgs_per_bh, need16 = 16 + (int64_t)t.wgs_per_bh * cmhsa_t16::kWaves * t.jobs_per_wave;
+        if (!out || cap < need16) return (int)need16;
+        const int header16[16] = {cmhsa_t16::kWaves, t.jobs_per_wave, t.wgs_per_bh, (int)((total + 7) / 8 * 8), 1, 1, 0, 0, t.tiles_per_wave,
+                                  t.n16, 2, 0, 0, 0, 0, 0};
+        memcpy(out, header16, sizeof(header16));
+        for (int64_t i = 0; i < need16 - 16; ++i) out[16 + i] = (int)t.table[i];
+        return (int)need16;
+    }
     dim3 grid;
     const int grid_rc = plan_grid(plan, bh, grid);
     if (grid_rc != CMHSA_OK) return grid_rc;

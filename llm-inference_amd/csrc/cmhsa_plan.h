@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "cmhsa_common.h"
+#include "cmhsa_tiles16.h"
 
 namespace {
 
@@ -51,6 +52,8 @@ struct Plan {
     const char *family = "analytic";
     int segs = 4;                                // table plans: segments per workgroup record (4 or 8)
     unsigned table[kTableSize];                  // table plans: Params::seg_table
+    bool tiles16 = false;                        // the 16-row-block family (cmhsa_fwd16.hip): everything above but cycles / family is unused
+    cmhsa_t16::Plan16 t16;
 };
 
 inline unsigned seg_word0(int n, int lo, int cnt, unsigned mask) { return (unsigned)n | ((unsigned)lo << 8) | ((unsigned)cnt << 16) | (mask << 24); }
@@ -399,7 +402,7 @@ int device_cu_count(int dev) {
     return n;
 }
 
-Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
+Plan choose_plan(int64_t bh, int nqb, int seq_len_hint, int cus, bool allow_split) {
     static const int forced_waves = env_int("CMHSA_WAVES", 0);
     static const int forced_chain = env_int("CMHSA_CHAIN", 0);
     static const int forced_table = env_int("CMHSA_TABLE", -1);
@@ -531,6 +534,25 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
             have = true;
         }
     }
+    //   (d) 16-row blocks on v_mfma_f32_16x16x4_f32 (cmhsa_fwd16.hip): four-wave workgroups, one per CU, every wave a list
+    //       of jobs cut so that all SIMDs carry the same number of 16 x 16 tiles; no LDS staging, no prologue barrier.
+    //       Grids of one round (bh <= CUs, T <= 4080): a quarter of the 32 x 32 unit's quantum and half its fixed cost.
+    {
+        static const int forced_t16 = env_int("CMHSA_T16", -1);      // -1 = planner's choice, 0 = never, 1 = wherever it applies
+        const int n16 = (seq_len_hint + 15) / 16;
+        Plan t;
+        if (forced_t16 != 0 && !forced_old && !forced_packed && forced_waves != 1 && cmhsa_t16::make_plan(bh, n16, cus, t.t16) &&
+            (forced_t16 == 1 || !have || t.t16.cycles < best.cycles * 0.97)) {
+            t.tiles16 = true;
+            t.pp = pack_plan(nqb, cmhsa_t16::kWaves);
+            t.pp.wgs_per_bh = t.n_wgs = t.t16.wgs_per_bh;
+            t.single_round = true;
+            t.cycles = t.t16.cycles;
+            t.family = "16-row blocks, job lists";
+            best = t;
+            have = true;
+        }
+    }
     static const bool verbose = env_int("CMHSA_VERBOSE", 0) != 0;
     if (verbose)
         fprintf(stderr, "cmhsa plan: bh=%lld nqb=%d cus=%d -> %s, waves=%d chain=%d simd cap=%d wgs/bh=%d split blocks/bh=%d est=%.0f cycles\n",
@@ -551,15 +573,17 @@ Plan choose_plan(int64_t bh, int nqb, int cus, bool allow_split) {
 
 // choose_plan() prices dozens of candidates; calls repeat the same few shapes, so the result is memoised per
 // (shape, CU count of the device the call runs on, workspace available or not)
-Plan cached_plan(int64_t bh, int nqb, int cus, bool allow_split) {
-    struct Entry { int64_t bh; int nqb, cus; bool allow_split; Plan plan; };
+// (seq_len: the 16-row family's block count is ceil(T / 16) -- two per 32-row block, or one fewer; the other families use nqb only)
+Plan cached_plan(int64_t bh, int seq_len, int cus, bool allow_split) {
+    const int nqb = (seq_len + kQBlock - 1) / kQBlock, n16 = (seq_len + 15) / 16;
+    struct Entry { int64_t bh; int nqb, n16, cus; bool allow_split; Plan plan; };
     static std::mutex mu;
     static std::vector<Entry> cache;
     std::lock_guard<std::mutex> lock(mu);
     for (const Entry &e : cache)
-        if (e.bh == bh && e.nqb == nqb && e.cus == cus && e.allow_split == allow_split) return e.plan;
+        if (e.bh == bh && e.nqb == nqb && e.n16 == n16 && e.cus == cus && e.allow_split == allow_split) return e.plan;
     if (cache.size() >= 256) cache.clear();
-    cache.push_back(Entry{bh, nqb, cus, allow_split, choose_plan(bh, nqb, cus, allow_split)});
+    cache.push_back(Entry{bh, nqb, n16, cus, allow_split, choose_plan(bh, nqb, seq_len, cus, allow_split)});
     return cache.back().plan;                        // by value: the entry may be gone once the lock is released
 }
 
