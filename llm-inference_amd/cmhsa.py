@@ -162,12 +162,14 @@ def plan_dump(batch: int, seq_len: int, num_heads: int, with_workspace: bool = F
     plan = dict(zip(names, buf[:16]))
     if plan["use_table"] == 2:
         # the 16-row-block family (csrc/cmhsa_tiles16.h): "segs" = job words per wave, "nqb" = 16-row blocks per (b,h),
-        # "simd_cap" = tiles on the longest wave; per workgroup four waves, per wave its jobs as
-        # (block, first_tile, tiles, rank, pieces); "merges" = per workgroup, the barrier flag of each wave's first word
-        J = plan["segs"]
-        plan.update(family="tiles16", jobs_per_wave=J, n16=plan["nqb"], tiles_per_wave=plan["simd_cap"])
-        words = [[[buf[16 + (j * 4 + w) * J + i] & 0xffffffff for i in range(J)] for w in range(4)] for j in range(plan["wgs_per_bh"])]
-        plan["workgroups"] = [[[(x & 255, (x >> 8) & 255, (x >> 16) & 255, (x >> 24) & 3, (x >> 26) & 7) for x in wave if (x >> 16) & 255]
+        # "simd_cap" = tiles on the busiest SIMD; per workgroup its 4 or 8 job lists in run order (with 8 waves the lists
+        # 2s and 2s + 1 share SIMD s), per list its jobs as (block, first_tile, tiles, rank, pieces); "merges" = per
+        # workgroup, the barrier flag of each list's first word
+        J, W = plan["segs"], plan["waves"]
+        plan.update(family="tiles16", jobs_per_wave=J, blocks=plan["nqb"], tiles_per_simd=plan["simd_cap"], sub=plan["chain"],
+                    contig=bool(plan["n_paired"]))
+        words = [[[buf[16 + (j * W + w) * J + i] & 0xffffffff for i in range(J)] for w in range(W)] for j in range(plan["wgs_per_bh"])]
+        plan["workgroups"] = [[[(x & 255, (x >> 8) & 255, (x >> 16) & 255, (x >> 24) & 7, (x >> 27) & 15) for x in wave if (x >> 16) & 255]
                                for wave in wg] for wg in words]
         plan["merges"] = [[bool(wave[0] >> 31) for wave in wg] for wg in words]
         plan["raw_words"] = words

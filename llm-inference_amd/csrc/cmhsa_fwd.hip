@@ -958,9 +958,9 @@ int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspac
     const int cus = device_cu_count(dev);
     const Plan pl = cached_plan(bh, seq_len, cus, with_workspace != 0);
     if (pl.tiles16) {
-        snprintf(buf, (size_t)buf_len, "%s: 4-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, %d 16-row blocks per (b,h), at most %d tiles "
-                 "and %d jobs per wave, workspace 0 B, estimate %.0f cycles", pl.family, pl.t16.wgs_per_bh, (long long)bh, cus, pl.t16.n16,
-                 pl.t16.tiles_per_wave, pl.t16.max_jobs, pl.cycles);
+        snprintf(buf, (size_t)buf_len, "%s: %d-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, %d query blocks per (b,h), at most %d tiles "
+                 "per SIMD and %d jobs per wave, %s grid, workspace 0 B, estimate %.0f cycles", pl.family, pl.t16.waves, pl.t16.wgs_per_bh,
+                 (long long)bh, cus, pl.t16.blocks, pl.t16.tiles_per_simd, pl.t16.max_jobs, pl.t16.contig ? "XCD-contiguous" : "2-D", pl.cycles);
         return CMHSA_OK;
     }
     snprintf(buf, (size_t)buf_len, "%s: %d-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, chain cap %d, SIMD cap %d, "
@@ -981,13 +981,15 @@ int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, i
     }
     const Plan plan = cached_plan(bh, seq_len, cus, with_workspace != 0);
     if (plan.tiles16) {
-        // the 16-row-block family: header as below with out[1] = job words per wave, out[10] = 2, out[9] = 16-row blocks;
-        // then, per workgroup of a (b,h) and per wave, its job words as they are (cmhsa_tiles16.h)
+        // the 16-key-tile family: header as below with out[1] = job words per wave, out[8] = tiles on the busiest SIMD,
+        // out[9] = query blocks, out[10] = 2, out[12] = 16-row halves per block, out[13] = XCD-contiguous grid; then, per
+        // workgroup of a (b,h) and per job list (run order), its job words as they are (cmhsa_tiles16.h)
         const cmhsa_t16::Plan16 &t = plan.t16;
-        const int64_t total = bh * t.wgs_per_bh, need16 = 16 + (int64_t)t.wgs_per_bh * cmhsa_t16::kWaves * t.jobs_per_wave;
+        const int J = cmhsa_t16::kWordsPerWg / t.waves;
+        const int64_t total = bh * t.wgs_per_bh, need16 = 16 + (int64_t)t.wgs_per_bh * cmhsa_t16::kWordsPerWg;
         if (!out || cap < need16) return (int)need16;
-        const int header16[16] = {cmhsa_t16::kWaves, t.jobs_per_wave, t.wgs_per_bh, (int)((total + 7) / 8 * 8), 1, 1, 0, 0, t.tiles_per_wave,
-                                  t.n16, 2, 0, 0, 0, 0, 0};
+        const int header16[16] = {t.waves, J, t.wgs_per_bh, t.contig ? (int)((total + 7) / 8 * 8) : t.wgs_per_bh, t.contig ? 1 : (int)bh, 1, 0, 0,
+                                  t.tiles_per_simd, t.blocks, 2, 0, t.sub, t.contig ? 1 : 0, 0, 0};
         memcpy(out, header16, sizeof(header16));
         for (int64_t i = 0; i < need16 - 16; ++i) out[16 + i] = (int)t.table[i];
         return (int)need16;

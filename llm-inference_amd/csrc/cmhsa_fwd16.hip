@@ -1,32 +1,39 @@
-// cmhsa_fwd16.hip -- the "16-row blocks" family of the fp32 causal attention forward for MI355X (gfx950 / CDNA4).
+// cmhsa_fwd16.hip -- the "16-key tiles" family of the fp32 causal attention forward for MI355X (gfx950 / CDNA4).
 //
 // Same function as cmhsa_fwd.hip (reference torch_extensions/causal_multihead_self_attention/
 // causal_multihead_self_attention.cu:64-405, "CMHSA.cu"; the naive formula of reference causal_self_attention.py:173-194):
 //     O[b, :, 64h:64h+64] = softmax(mask(Q_h K_h^T) / 8) V_h ,  key j <= query i,
 // decomposed for grids that fit the chip in ONE round (BASELINE config 2, and the B = 1 launches of a generation, config 3),
 // where the kernel of cmhsa_fwd.hip pays for its 32 x 32 units: a query block's keys can only be spread over the four
-// SIMDs of one CU, the work comes in quanta of 4 096 MFMA cycles, and the prologue (K and Q through LDS, a barrier)
-// and merge are 7-9 k cycles of a 12-40 k cycle launch (profiles/r03_experiments/stamps_b1_h12_t*.txt).  Here:
-//   * query blocks of 16 rows, key tiles of 16 rows, v_mfma_f32_16x16x4_f32 (same flop rate as the 32x32x2 shape): a
-//     tile is 16 QK + 16 PV MFMAs = 1 024 cycles, a quarter of a unit, and a block's tiles need half the SIMD time;
+// SIMDs of one CU, the work comes in quanta of 4 096 MFMA cycles -- 7 units on the busiest SIMD of config 2 where an even
+// spread is 6.19 --, and the prologue (K and Q through LDS, a barrier) and merge are 7-9 k cycles of a 12-40 k cycle launch
+// (profiles/r03_experiments/baseline_r02_kernel_stamps_*.txt).  Here:
+//   * key tiles of 16 rows on v_mfma_f32_16x16x4_f32 (same flop rate as the 32x32x2 shape).  A query block is 16 rows
+//     (kSub = 1: a tile is 16 QK + 16 PV MFMAs = 1 024 cycles, a quarter of a unit; for the small grids of a generation,
+//     where a block's tiles then need half the SIMD time) or two 16-row halves that share every K and V register
+//     (kSub = 2: the arithmetic intensity of the 32-row kernel -- with one half per load the family asks the L2 for
+//     32 B/clk/CU, more than it delivers -- at half its quantum);
 //   * S^T = K Q^T again: the query sits on the lane (l % 16), the S^T accumulator registers are, as they stand, the B
 //     operand of O^T += V^T P^T; row max / sum cross the four lane groups with v_permlane16_swap + v_permlane32_swap
 //     (the wave64 counterpart of the reference's 16-lane __shfl_down_sync tree, CMHSA.cu:267-284);
 //   * no LDS and no barrier in front of the first MFMA: K and Q fragments go straight from global memory into the
 //     A / B operand layout (lane (g, r) reads the 16-B piece 4c + g of row r: every row's four lanes cover 64
 //     contiguous bytes), V likewise (lane (g, r) reads floats 4r..4r+3 of key 4g + i: whole 256-B rows);
-//   * a workgroup = four waves, one per SIMD.  Each wave runs a LIST of jobs from a host-made table (cmhsa_tiles16.h):
-//     a job = a run of key tiles of one block.  The blocks of a workgroup are laid end to end and cut into four equal
-//     runs, so all four SIMDs carry the same number of tiles; a block cut by a run boundary is merged through LDS
-//     behind the kernel's only barrier, a whole block is normalised and stored straight from the accumulators;
-//   * K / V tiles are prefetched two steps (of two tiles) ahead into registers, across job boundaries; the next job's
-//     query fragments are requested at the start of the current job;
+//   * a workgroup = four waves (one per SIMD) or eight (two per SIMD: one covers the other's memory waits), one
+//     workgroup per CU.  Each wave runs a LIST of jobs from a host-made table (cmhsa_tiles16.h): a job = a run of key
+//     tiles of one block.  The blocks of a workgroup are laid end to end and cut into four equal runs, one per SIMD (halved
+//     between its two waves), so all SIMDs carry the same number of tiles; a block cut by a run boundary is merged
+//     through LDS behind the kernel's only barrier, a whole block is normalised and stored straight from the accumulators;
+//   * K / V of the next step (two tiles) are requested as soon as the registers of the current one fall free (K behind
+//     each tile's QK chain, V behind each PV k-step), across job boundaries; the next job's query fragments are requested
+//     at the start of the current job;
 //   * online softmax in the log2 domain, deferred normalisation, speculative lazy rescale -- as in cmhsa_fwd.hip.
-// Causal early exit (CMHSA.cu:133-136) = the table never names a tile past the diagonal one.
+// Causal early exit (CMHSA.cu:133-136) = the table never names a tile past a block's last diagonal tile.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <type_traits>
@@ -44,9 +51,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kHeadDim = 64;
 constexpr float kScaleLog2 = 0.18033688011112042f;        // log2(e) / sqrt(64)
 constexpr float kRescaleSum = 1.8446744e19f;              // 2^64: a row sum of P above it triggers the rescale path
-// LDS: [wave][slot A, B][image: [4 rows i][64 lanes] float4 | (m, l) of the 16 queries]
+// LDS: [list u][slot A, B][per half: image [4 rows i][64 lanes] float4] [per half: (m, l) of the 16 queries]
 constexpr int kImageFloats = 4 * 64 * 4;
-constexpr int kSlotFloats = kImageFloats + 32;
+constexpr int slot_floats(int sub) { return sub * (kImageFloats + 32); }
+constexpr int lds_bytes(int sub, int waves) { return waves * 2 * slot_floats(sub) * 4; }        // 33 KiB .. 132 KiB
 
 struct Params16 {
     const float *q, *k, *v;
@@ -56,7 +64,7 @@ struct Params16 {
     int seq_len, num_heads;
     int wgs_per_bh, total_wgs, per_xcd; // workgroups per (b,h); bh * wgs_per_bh; ceil(total_wgs / 8)
     unsigned heads_magic, wgs_magic;    // floor((2^32-1) / num_heads), / wgs_per_bh
-    unsigned table[kTableWords];        // [workgroup of a (b,h)][wave][kJobs] job words (cmhsa_tiles16.h)
+    unsigned table[kTableWords];        // [workgroup of a (b,h)][list u][32 / waves] job words (cmhsa_tiles16.h)
 };
 
 #ifdef CMHSA_STAMPS
@@ -111,32 +119,47 @@ __device__ __forceinline__ f32x4 load16(__amdgpu_buffer_rsrc_t rsrc, int voffset
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, 0, 0));
 }
 
-template <int kJobs>
-__global__ __launch_bounds__(kWaves * 64, 1) void fwd16_kernel(Params16 p) {
-    __shared__ __attribute__((aligned(16))) float lds[kWaves * 2 * kSlotFloats];
+// kSub: 16-row halves per query block.  kWaves: 4 or 8 waves per workgroup (32 / kWaves jobs per wave).
+// kContig: the workgroup -> (b,h) map (cmhsa_tiles16.h, Plan16::contig).
+template <int kSub, int kWaves, bool kContig>
+__global__ __launch_bounds__(kWaves * 64, 2) void fwd16_kernel(Params16 p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // kWaves * 2 * slot_floats(kSub)
+    constexpr int kJobs = kWordsPerWg / kWaves;
+    constexpr int kSlot = slot_floats(kSub);
+    constexpr int kBlockRows = 16 * kSub;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = kWaves == 8 ? 2 * (wave & 3) + (wave >> 2) : wave;       // this wave's job list, in run order (cmhsa_tiles16.h)
     const int g = lane >> 4, r = lane & 15;      // lane group (k index of both MFMA operands), row / query within the tile
 #ifdef CMHSA_STAMPS
-    const bool stamp_on = g_stamp_buf != nullptr && (int)blockIdx.x == g_stamp_block && lane == 0;
+    const int lin_block = blockIdx.x + gridDim.x * blockIdx.y;
+    const bool stamp_on = g_stamp_buf != nullptr && lin_block == g_stamp_block && lane == 0;
     unsigned long long *stamp_ptr = g_stamp_buf + wave * 128;
     int stamp_i = 4;
     STAMP(0);
-    if (g_block_times && threadIdx.x == 0) g_block_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (g_block_times && threadIdx.x == 0) g_block_times[2 * lin_block] = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // ---- workgroup -> (b,h), workgroup j of it.  Workgroups are dealt round-robin over the 8 XCDs in linear order, so
-    //      XCD x gets the ids x, x + 8, ...: it is given a CONTIGUOUS run of the (b,h)-major workgroup list, so that a
-    //      (b,h)'s K and V are read through one XCD's L2 (two at a boundary), whatever B*H is. ----
-    const int id = blockIdx.x;
-    const int pos = (id & 7) * p.per_xcd + (id >> 3);
-    if (pos >= p.total_wgs) return;                       // padding of the last XCDs' runs (whole workgroup, before any barrier)
-    const int bh = udiv_magic(pos, p.wgs_per_bh, p.wgs_magic), j = pos - bh * p.wgs_per_bh;
-    // every kernel argument and this wave's job words in one batch of scalar loads (one wait)
+    // ---- workgroup -> (b,h), workgroup j of it.
+    //      kContig: workgroups are dealt round-robin over the 8 XCDs in linear order, so XCD x gets the ids x, x + 8, ...:
+    //      it is given a CONTIGUOUS run of the (b,h)-major workgroup list, so that a (b,h)'s K and V are read through one
+    //      XCD's L2 (two at a boundary), whatever B*H is.  Else grid = (workgroup, (b,h)): j comes with the wave, and this
+    //      wave's job words ride in the first batch of scalar loads (short launches: one round trip less). ----
+    int bh, j;
+    if constexpr (kContig) {
+        const int id = blockIdx.x;
+        const int pos = (id & 7) * p.per_xcd + (id >> 3);
+        if (pos >= p.total_wgs) return;                   // padding of the last XCDs' runs (whole workgroup, before any barrier)
+        bh = udiv_magic(pos, p.wgs_per_bh, p.wgs_magic);
+        j = pos - bh * p.wgs_per_bh;
+    } else {
+        j = blockIdx.x;
+        bh = blockIdx.y;
+    }
     unsigned jw[kJobs];
 #pragma unroll
-    for (int i = 0; i < kJobs; ++i) jw[i] = p.table[(j * kWaves + wave) * kJobs + i];
+    for (int i = 0; i < kJobs; ++i) jw[i] = p.table[j * kWordsPerWg + u * kJobs + i];
     if constexpr (kJobs == 8)
         asm volatile("" ::"s"(jw[4]), "s"(jw[5]), "s"(jw[6]), "s"(jw[7]));
     asm volatile("" ::"s"(jw[0]), "s"(jw[1]), "s"(jw[2]), "s"(jw[3]), "s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs),
@@ -157,257 +180,248 @@ __global__ __launch_bounds__(kWaves * 64, 1) void fwd16_kernel(Params16 p) {
     for (int i = 0; i < kJobs; ++i) jobs_v = lane == i ? jw[i] : jobs_v;
     auto job = [&](int i) { return (unsigned)__builtin_amdgcn_readlane((int)jobs_v, i); };
     const bool wg_merges = (jw[0] & kWgMergesBit) != 0;
-    int total_steps = 0;                                   // a step = two tiles of a job (its last step: one, if the run is odd)
+    int njobs = 0;
     unsigned word_a = 0, word_b = 0;                       // this wave's pieces of cut blocks: a later piece (slot A), a first piece (slot B)
 #pragma unroll
     for (int i = 0; i < kJobs; ++i) {
         const int cnt = (jw[i] >> 16) & 255;
-        total_steps += (cnt + 1) >> 1;
-        if (cnt && ((jw[i] >> 26) & 7) > 1) {
-            if ((jw[i] >> 24) & 3) word_a = jw[i]; else word_b = jw[i];
+        njobs += cnt ? 1 : 0;
+        if (cnt && ((jw[i] >> 27) & 15) > 1) {
+            if ((jw[i] >> 24) & 7) word_a = jw[i]; else word_b = jw[i];
         }
     }
 
-    // per-lane byte offsets inside a step's 32 rows
-    const int koff0 = (r * (int)p.k_rs + 4 * g) * 4, koff1 = koff0 + 16 * (int)p.k_rs * 4;       // K: row r (+16), piece 4c + g: + 64 c
-    int voff[2][4];                                                                              // V: key 4g + i (+16), floats 4r..4r+3
+    // per-lane byte offsets inside a step's 32 rows, every one in a register of its own (an add of a constant that the
+    // compiler hoists out of the loop is no longer folded into the instruction's offset field)
+    int koffs[2][4], voffs[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        voff[0][i] = ((4 * g + i) * (int)p.v_rs + 4 * r) * 4;
-        voff[1][i] = voff[0][i] + 16 * (int)p.v_rs * 4;
+    for (int c = 0; c < 4; ++c) {
+        koffs[0][c] = (r * (int)p.k_rs + 4 * g + 16 * c) * 4;                       // K: row r (+16), floats 16c + 4g .. +3
+        koffs[1][c] = koffs[0][c] + 16 * (int)p.k_rs * 4;
+        voffs[0][c] = ((4 * g + c) * (int)p.v_rs + 4 * r) * 4;                      // V: key 4g + i (+16), floats 4r .. 4r+3
+        voffs[1][c] = voffs[0][c] + 16 * (int)p.v_rs * 4;
     }
     const int qoff = (r * (int)p.q_rs + 4 * g) * 4;
 
-    // ---- prefetch cursor: the key tiles of the wave's jobs, in order, two at a time ----
-    int pf_job = -1, pf_tile = 0, pf_end = 0;
-    auto pf_take = [&](bool &en) {
-        if (pf_tile >= pf_end) {
-            pf_job = min(pf_job + 1, kJobs);                // (lane kJobs holds "no job": the cursor stays exhausted)
-            const unsigned w = job(pf_job);
-            pf_tile = (w >> 8) & 255;
-            pf_end = pf_tile + ((w >> 16) & 255);
-        }
-        en = pf_tile < pf_end;
-        const int row0 = pf_tile * 16;
-        pf_tile += 2;
-        return row0;
-    };
-
-    f32x4 kx[2][4], ky[2][4];        // K of two steps in flight: [tile of the step][c] = floats 16c + 4g .. +3 of key r
-    f32x4 vx[2][4], vy[2][4];        // V:                       [tile][i] = floats 4r .. 4r+3 of key 4g + i
-    f32x4 qn[4];                     // the NEXT job's query fragments, raw
-    auto load_step = [&](f32x4 (&kb)[2][4], f32x4 (&vb)[2][4]) {
-        bool en;
-        const int row0 = pf_take(en);
-        const __amdgpu_buffer_rsrc_t ks = rows_rsrc(kg, p.k_rs, row0, 32, N, en), vs = rows_rsrc(vg, p.v_rs, row0, 32, N, en);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            kb[0][c] = load16(ks, koff0 + 64 * c);
-            kb[1][c] = load16(ks, koff1 + 64 * c);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vb[0][i] = load16(vs, voff[0][i]);
-            vb[1][i] = load16(vs, voff[1][i]);
-        }
-    };
+    f32x4 kb[2][4];                  // K of the step: [tile][c] = floats 16c + 4g .. +3 of key r
+    f32x4 vb[2][4];                  // V of the step: [tile][i] = floats 4r .. 4r+3 of key 4g + i
+    f32x4 qn[kSub][4];               // the NEXT job's query fragments, raw: [half][c]
     auto load_q = [&](unsigned w) {
         const bool en = ((w >> 16) & 255) != 0;
-        const __amdgpu_buffer_rsrc_t qs = rows_rsrc(qg, p.q_rs, (int)(w & 255) * 16, 16, N, en);
+        const __amdgpu_buffer_rsrc_t qs = rows_rsrc(qg, p.q_rs, (int)(w & 255) * kBlockRows, kBlockRows, N, en);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qn[c] = load16(qs, qoff + 64 * c);
+        for (int s = 0; s < kSub; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qn[s][c] = load16(qs, qoff + (s * 16 * (int)p.q_rs + 16 * c) * 4);
     };
-    // one memory round trip ahead of the first MFMA: the first job's query fragments and the first two steps' K and V
-    load_q(jw[0]);
-    load_step(kx, vx);
-    load_step(ky, vy);
+    // one memory round trip ahead of the first MFMA, in the order of use: the first job's query fragments, its first
+    // step's K (tile A, then B), then V
+    {
+        load_q(jw[0]);
+        const int row0 = (int)((jw[0] >> 8) & 255) * 16;
+        const bool en = njobs > 0;
+        const __amdgpu_buffer_rsrc_t ks = rows_rsrc(kg, p.k_rs, row0, 32, N, en), vs = rows_rsrc(vg, p.v_rs, row0, 32, N, en);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kb[t][c] = load16(ks, koffs[t][c]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vb[t][i] = load16(vs, voffs[t][i]);
+    }
     STAMP(121);
 
-    float qf[16];                    // Q^T fragment of the current job, pre-scaled: k-step 4c + jj uses d = 16c + 4g + jj
-    f32x4 acc[4];                    // O^T: acc[dt][i] <-> d = 16g + 4i + dt, query r
-    float m_run = -INFINITY, l_run = 0.f;
-    int cj = 0, ctile = 0, cend = 0, blk = 0;
-    unsigned cw = 0;
-    bool new_job = true;
-
-    float *my_slots = lds + wave * 2 * kSlotFloats;
-
-    auto do_step = [&](f32x4 (&kb)[2][4], f32x4 (&vb)[2][4]) __attribute__((always_inline)) {
-        if (new_job) {
-            cw = job(cj);
-            blk = cw & 255;
-            ctile = (cw >> 8) & 255;
-            cend = ctile + ((cw >> 16) & 255);
+    float *my_slots = lds + u * 2 * kSlot;
+    // the second-dispatched half of an 8-wave workgroup loses every arbitration against its SIMD partner (both at priority 0
+    // the older wave's chains run at 8.4 k cycles per step, the younger's at 13 k, and the younger finishes alone): one static
+    // priority step for waves 4-7 (MI355X guide, "Static priority for the younger half")
+    if constexpr (kWaves == 8) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
+    STAMP(1);
+    for (int ji = 0; ji < njobs; ++ji) {
+        const unsigned cw = job(ji), nw = job(ji + 1);       // (lane kJobs holds "no job")
+        const int blk = cw & 255, lo = (cw >> 8) & 255, hi = lo + (int)((cw >> 16) & 255);
+        const int nlo = (nw >> 8) & 255;
+        const bool have_next = ((nw >> 16) & 255) != 0;
+        float qf[kSub][16];          // Q^T fragments of the job, pre-scaled: k-step 4c + jj uses d = 16c + 4g + jj
+#pragma unroll
+        for (int s = 0; s < kSub; ++s)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) qf[4 * c + jj] = qn[c][jj] * kScaleLog2;
-            load_q(job(min(cj + 1, kJobs)));               // in flight for the whole of this job
+                for (int jj = 0; jj < 4; ++jj) qf[s][4 * c + jj] = qn[s][c][jj] * kScaleLog2;
+        load_q(nw);                  // in flight for the whole of this job
+        f32x4 acc[kSub][4];          // O^T: acc[s][dt][i] <-> d = 16g + 4i + dt, query r of half s
+        float m_run[kSub], l_run[kSub];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            m_run = -INFINITY;
-            l_run = 0.f;
+        for (int s = 0; s < kSub; ++s) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[s][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m_run[s] = -INFINITY;
+            l_run[s] = 0.f;
         }
-        const bool first = new_job;
-        new_job = false;
-        const bool diag = cend - 1 == blk && ctile + 2 >= cend;     // the step ends with the block's diagonal tile
-        // descriptors of the step after next (its K and V take this step's registers as they fall free)
-        bool en;
-        const int row0n = pf_take(en);
-        const __amdgpu_buffer_rsrc_t ksn = rows_rsrc(kg, p.k_rs, row0n, 32, N, en), vsn = rows_rsrc(vg, p.v_rs, row0n, 32, N, en);
-        // kTwo (compile time): the step has two tiles, A and B; else one (the last step of a run of odd length)
-        auto body = [&](auto two_c) __attribute__((always_inline)) {
-            constexpr bool kTwo = decltype(two_c)::value;
+
+        for (int t = lo; t < hi; t += 2) {
+            const bool first = t == lo;
+            // the step after this one: the job's next two tiles, else the next job's first two, else none
+            const bool more = t + 2 < hi;
+            const int row0n = (more ? t + 2 : nlo) * 16;
+            const bool en = more || have_next;
+            const __amdgpu_buffer_rsrc_t ksn = rows_rsrc(kg, p.k_rs, row0n, 32, N, en), vsn = rows_rsrc(vg, p.v_rs, row0n, 32, N, en);
+            // the step's second tile is absent at the end of a run of odd length: its MFMAs are skipped (wave-uniform
+            // branches that define nothing but the chain's own result; every load stays outside them, so that the
+            // loop-carried K / V registers have ONE definition each and the compiler keeps them where they are)
+            const bool has_b = t + 1 < hi;
+            constexpr int kPar = kSub == 1 ? 2 : 1;          // one half per block: its even and odd k-steps as two chains
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i);
 #endif
-            // ---- S^T[key][query] = sum_d K[key][d] Q[query][d]: two independent chains (the shape's dependent latency
-            //      is 40 cycles against 32 of issue): tiles A and B, or the even / odd k-steps of a single tile ----
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+            // ---- S^T[key][query] = sum_d K[key][d] Q[query][d], tile A then tile B; at least two independent chains in
+            //      turn (the shape's dependent latency is 40 cycles against 32 of issue).  Behind a tile's chain: K of
+            //      the next step into its registers (the softmax and the PV chain to land). ----
+            f32x4 sc[kSub][2];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if constexpr (kTwo) {
+            for (int tl = 0; tl < 2; ++tl) {
+                f32x4 ch[kSub][kPar];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[0][c][jj], qf[4 * c + jj], sa, 0, 0, 0);
-                        sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[1][c][jj], qf[4 * c + jj], sb, 0, 0, 0);
-                    }
-                } else {
+                for (int s = 0; s < kSub; ++s)
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj += 2) {
-                        sa = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[0][c][jj], qf[4 * c + jj], sa, 0, 0, 0);
-                        sb = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[0][c][jj + 1], qf[4 * c + jj + 1], sb, 0, 0, 0);
-                    }
+                    for (int q2 = 0; q2 < kPar; ++q2) ch[s][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (tl == 0 || has_b) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int s = 0; s < kSub; ++s)
+                                ch[s][jj % kPar] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[tl][c][jj], qf[s][4 * c + jj], ch[s][jj % kPar], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kb[tl][c] = load16(ksn, koffs[tl][c]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < kSub; ++s) sc[s][tl] = kPar == 2 ? ch[s][0] + ch[s][kPar - 1] : ch[s][0];
             }
-            if constexpr (!kTwo) sa += sb;
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 1);
 #endif
-            // ---- causal mask: only the diagonal tile has key > query pairs (CMHSA.cu:228, :249); keys past the sequence
-            //      end exist in that tile only and are masked with it ----
-            if (diag) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (4 * g + i > r) {
-                        if constexpr (kTwo) sb[i] = -INFINITY; else sa[i] = -INFINITY;
+            for (int s = 0; s < kSub; ++s) {
+                // ---- causal mask (CMHSA.cu:228, :249): tile kSub * blk + s is the diagonal tile of half s (key > query
+                //      pairs; keys past the sequence end exist in a diagonal tile only and are masked with it), the
+                //      block's later tile is all masked for half 0; so is an absent tile B ----
+                const int dtile = kSub * blk + s;
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    if (t + tl >= dtile || (tl == 1 && !has_b)) {                    // wave-uniform
+                        const bool all = t + tl > dtile || (tl == 1 && !has_b);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (all || 4 * g + i > r) sc[s][tl][i] = -INFINITY;
                     }
                 }
             }
             // ---- online softmax, log2 domain, speculative against the old running max (see cmhsa_fwd.hip): the max is
             //      only computed on a job's first step and when some row sum leaves [0, 2^64) ----
-            f32x4 pa, pb = {0.f, 0.f, 0.f, 0.f};
-            float psum = 0.f;
-            bool redo = first;
-            if (!first) {
+            f32x4 pr[kSub][2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    pa[i] = __builtin_amdgcn_exp2f(sa[i] - m_run);
-                    psum += pa[i];
-                    if constexpr (kTwo) {
-                        pb[i] = __builtin_amdgcn_exp2f(sb[i] - m_run);
-                        psum += pb[i];
-                    }
+            for (int s = 0; s < kSub; ++s) {
+                float psum = 0.f;
+                bool redo = first;
+                if (!first) {
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            pr[s][tl][i] = __builtin_amdgcn_exp2f(sc[s][tl][i] - m_run[s]);
+                            psum += pr[s][tl][i];
+                        }
+                    redo = !__all(psum < kRescaleSum);      // NaN and inf compare false: they take the max path too
                 }
-                redo = !__all(psum < kRescaleSum);          // NaN and inf compare false: they take the max path too
-            }
-            if (redo) {
-                float mx = fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3]));
-                if constexpr (kTwo) mx = fmaxf(mx, fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3])));
-                mx = x32_max(x16_max(mx));
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 0 on a job's first step (m_run = -inf)
-                l_run *= alpha;
-                m_run = m_new;
+                if (redo) {
+                    float mx = fmaxf(fmaxf(fmaxf(sc[s][0][0], sc[s][0][1]), fmaxf(sc[s][0][2], sc[s][0][3])),
+                                     fmaxf(fmaxf(sc[s][1][0], sc[s][1][1]), fmaxf(sc[s][1][2], sc[s][1][3])));
+                    mx = x32_max(x16_max(mx));
+                    const float m_new = fmaxf(m_run[s], mx);
+                    // a piece that holds only masked keys for this half (the block's last tile, half 0) stays EMPTY:
+                    // (m, l, O) = (-inf, 0, 0) -- the partial that CMHSA.cu:45-48 handles with its sum == 0 branches
+                    const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[s] - m_ref);       // 0 on a job's first step (m_run = -inf)
+                    l_run[s] *= alpha;
+                    m_run[s] = m_new;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) acc[dt] *= alpha;
-                psum = 0.f;
+                    for (int dt = 0; dt < 4; ++dt) acc[s][dt] *= alpha;
+                    psum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    pa[i] = __builtin_amdgcn_exp2f(sa[i] - m_new);
-                    psum += pa[i];
-                    if constexpr (kTwo) {
-                        pb[i] = __builtin_amdgcn_exp2f(sb[i] - m_new);
-                        psum += pb[i];
-                    }
+                    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            pr[s][tl][i] = __builtin_amdgcn_exp2f(sc[s][tl][i] - m_ref);
+                            psum += pr[s][tl][i];
+                        }
                 }
+                l_run[s] += psum;
             }
-            l_run += psum;
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 2);
 #endif
             // ---- O^T[d][query] += sum_key V[key][d] P[query][key]: k-step (tile, i) pairs the keys 4g + i of the four
-            //      lane groups, which is where register i of the S^T accumulator holds them: P feeds the B operand as
-            //      it stands.  Behind each k-step's four MFMAs: the loads of the step after next into the registers
-            //      that just fell free (a one-tile step never touched its B registers: they are reloaded beside A's). ----
+            //      lane groups, which is where register i of the S^T accumulator holds them: P feeds the B operand as it
+            //      stands.  Behind each k-step's MFMAs: V of the next step into the registers that just fell free. ----
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[0][i][dt], pa[i], acc[dt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                vb[0][i] = load16(vsn, voff[0][i]);
-                kb[0][i] = load16(ksn, koff0 + 64 * i);
-                if constexpr (!kTwo) {
-                    vb[1][i] = load16(vsn, voff[1][i]);
-                    kb[1][i] = load16(ksn, koff1 + 64 * i);
-                }
-            }
-            if constexpr (kTwo) {
+            for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     __builtin_amdgcn_sched_barrier(0);
+                    if (tl == 0 || has_b) {
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[1][i][dt], pb[i], acc[dt], 0, 0, 0);
+                        for (int s = 0; s < kSub; ++s)
+#pragma unroll
+                            for (int dt = 0; dt < 4; ++dt)
+                                acc[s][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[tl][i][dt], pr[s][tl][i], acc[s][dt], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
-                    vb[1][i] = load16(vsn, voff[1][i]);
-                    kb[1][i] = load16(ksn, koff1 + 64 * i);
+                    vb[tl][i] = load16(vsn, voffs[tl][i]);
                 }
-            }
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 3);
             stamp_i += 4;
 #endif
-        };
-        if (cend - ctile >= 2) body(std::true_type{}); else body(std::false_type{});
-        ctile += 2;
-        if (ctile >= cend) {
-            // ---- the job is done.  A whole block: normalise and store, lane (g, r) = query r, floats 16g + 4i .. + 3.
-            //      A piece of a cut block: the un-normalised image and (m, l) go to one of the wave's two LDS slots
-            //      (a piece that starts its block: slot B, a later piece: slot A) for the merge behind the barrier. ----
-            const float l_tot = x32_sum(x16_sum(l_run));
-            const int pieces = (cw >> 26) & 7;
+        }
+
+        // ---- the job is done.  A whole block: normalise and store, lane (g, r) = query r, floats 16g + 4i .. + 3.
+        //      A piece of a cut block: the un-normalised image and (m, l) go to one of the list's two LDS slots (a piece
+        //      that starts its block: slot B, a later piece: slot A) for the merge behind the barrier. ----
+        const int pieces = (cw >> 27) & 15;
+        float *slot = my_slots + (((cw >> 24) & 7) ? 0 : kSlot);
+#pragma unroll
+        for (int s = 0; s < kSub; ++s) {
+            const float l_tot = x32_sum(x16_sum(l_run[s]));
             if (pieces <= 1) {
                 const float inv = 1.0f / l_tot;
-                const int row = blk * 16 + r;
+                const int row = blk * kBlockRows + 16 * s + r;
                 if (row < N) {
                     float *dst = og + (uint64_t)(uint32_t)row * p.o_rs + 16 * g;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        *reinterpret_cast<f32x4 *>(dst + 4 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * inv;
+                        *reinterpret_cast<f32x4 *>(dst + 4 * i) = f32x4{acc[s][0][i], acc[s][1][i], acc[s][2][i], acc[s][3][i]} * inv;
                 }
             } else {
-                float *slot = my_slots + (((cw >> 24) & 3) ? 0 : kSlotFloats);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<f32x4 *>(slot + (i * 64 + lane) * 4) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]};
-                if (g == 0) *reinterpret_cast<f32x2 *>(slot + kImageFloats + 2 * r) = f32x2{m_run, l_tot};
+                    *reinterpret_cast<f32x4 *>(slot + s * kImageFloats + (i * 64 + lane) * 4) = f32x4{acc[s][0][i], acc[s][1][i], acc[s][2][i], acc[s][3][i]};
+                if (g == 0) *reinterpret_cast<f32x2 *>(slot + kSub * kImageFloats + s * 32 + 2 * r) = f32x2{m_run[s], l_tot};
             }
-            ++cj;
-            new_job = true;
         }
-    };
-
-    STAMP(1);
-    for (int st = 0; st < total_steps; st += 2) {
-        do_step(kx, vx);
-        if (st + 1 < total_steps) do_step(ky, vy);
     }
     STAMP(2);
 
-    // ---- merge of the cut blocks: the g pieces of a block sit on consecutive waves (piece 0 in slot B of its wave, the
-    //      others in slot A of theirs); the wave of rank k combines rows i = k, k + g, ... of the image, pieces in order
-    //      (the bits do not depend on timing), divides by the merged l and stores. ----
+    // ---- merge of the cut blocks: the pieces of a block sit on consecutive lists (piece 0 in slot B of its list, the
+    //      others in slot A of theirs); the 4 kSub (half, image row) items go round-robin over the block's waves, each
+    //      combines its items' pieces in order (the bits do not depend on timing), divides by the merged l and stores. ----
     if (wg_merges) {
         __syncthreads();
         STAMP(120);
@@ -415,20 +429,22 @@ __global__ __launch_bounds__(kWaves * 64, 1) void fwd16_kernel(Params16 p) {
         for (int t = 0; t < 2; ++t) {
             const unsigned w = t == 0 ? word_a : word_b;
             if (!w) continue;                                                    // wave-uniform
-            const int mblk = w & 255, rank = (w >> 24) & 3, pieces = (w >> 26) & 7, wave0 = wave - rank;
-            const int row = mblk * 16 + r;
-            for (int i = rank; i < 4; i += pieces) {
+            const int mblk = w & 255, rank = (w >> 24) & 7, pieces = (w >> 27) & 15, u0 = u - rank;
+            for (int it = rank; it < 4 * kSub; it += pieces) {
+                const int s = it >> 2, i = it & 3;
+                const int row = mblk * kBlockRows + 16 * s + r;
+                // every piece's (m, l) and image row requested at once (absent pieces: (-inf, 0, 0))
                 float pm[kWaves], pl[kWaves];
                 f32x4 po[kWaves];
 #pragma unroll
                 for (int q = 0; q < kWaves; ++q) {
                     pm[q] = -INFINITY; pl[q] = 0.f; po[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (q < pieces) {                                            // wave-uniform
-                        const float *slot = lds + ((wave0 + q) * 2 + (q == 0 ? 1 : 0)) * kSlotFloats;
-                        const f32x2 ml = *reinterpret_cast<const f32x2 *>(slot + kImageFloats + 2 * r);
+                        const float *sl = lds + ((u0 + q) * 2 + (q == 0 ? 1 : 0)) * kSlot;
+                        const f32x2 ml = *reinterpret_cast<const f32x2 *>(sl + kSub * kImageFloats + s * 32 + 2 * r);
                         pm[q] = ml[0];
                         pl[q] = ml[1];
-                        po[q] = *reinterpret_cast<const f32x4 *>(slot + (i * 64 + lane) * 4);
+                        po[q] = *reinterpret_cast<const f32x4 *>(sl + s * kImageFloats + (i * 64 + lane) * 4);
                     }
                 }
                 float m_tot = pm[0];
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void fwd16_kernel(Params16 p) {
                 f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < kWaves; ++q) {
-                    const float f = __builtin_amdgcn_exp2f(pm[q] - m_tot);       // 0 for absent pieces (m = -inf)
+                    const float f = __builtin_amdgcn_exp2f(pm[q] - m_tot);       // 0 for an absent or empty piece (m = -inf)
                     l_tot += pl[q] * f;
                     sum += po[q] * f;
                 }
@@ -448,46 +464,53 @@ __global__ __launch_bounds__(kWaves * 64, 1) void fwd16_kernel(Params16 p) {
     }
 #ifdef CMHSA_STAMPS
     STAMP(3);
-    if (g_block_times && threadIdx.x == 0) g_block_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (g_block_times && threadIdx.x == 0) g_block_times[2 * lin_block + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
 }  // namespace
 
 // ---- host: the plan ---------------------------------------------------------------------------------------------------
-// Blocks (block t-1 has t tiles) go, longest first, to the workgroup of the (b,h) that carries the fewest tiles so far
-// (longest-processing-time-first: the loads end up within a tile or two of each other); a workgroup's blocks are laid
-// end to end in that order and cut into four runs of q = ceil(load / 4) tiles, one per wave.
-// Per-wave cost model (cycles), fitted to measured launch times (tools/run_t16.sh): a tile = 32 MFMAs of 32 cycles plus the
-// softmax arithmetic that cannot overlap them; a job = query fragments, a first step down the max path, a store or an LDS image.
-constexpr double kFixedCycles = 4500.0, kTileCycles = 1150.0, kJobCycles = 350.0;
+// Cost model (cycles at 2.4 GHz, on the scale of cmhsa_plan.h's single-round estimates: launch time minus ~1.7 k), fitted to
+// measured launch times (tools/run_t16_sweep.sh, profiles/r03_experiments/t16_*.log).  One wave per SIMD, 16-row blocks:
+// 9.5 k fixed + 1.3 k per tile on the busiest SIMD; a tile costs more once the launch's K and V (kv_mb, MiB) pass ~3 MiB --
+// every CU then streams at once and the memory side, not the matrix pipe, sets the pace (one 16-row half per load asks for
+// 32 B/clk/CU): + 250 cycles per tile and MiB.  Two halves per load (sub = 2) and two waves per SIMD are priced from their
+// own measurements.  A job = query fragments, a first step down the max path, a store or an LDS image.
+constexpr double kFixedCycles = 9500.0, kJobCycles = 300.0;
+static double tiles_cost(int sub, int waves, int tiles, double kv_mb) {
+    if (sub == 2) return 2900.0 * tiles + (waves == 8 ? 2000.0 : 3000.0);
+    return (1300.0 + 250.0 * std::max(0.0, kv_mb - 3.0)) * tiles + (waves == 8 ? 2000.0 : 0.0);
+}
 
-// Blocks (block t-1 has t tiles) -> the G workgroups of a (b,h).  method 0: longest first into the workgroup with the fewest
-// tiles so far (few blocks per workgroup, but the fullest ends up to a block above the mean when blocks are large against a
-// workgroup's share: T = 1024 on 21 workgroups, 109 tiles against a mean of 99); method 1: best fit decreasing into
-// workgroups of capacity C = the mean rounded up to the waves' quantum, C + 4, ... (reaches the mean; the last workgroup
+// Blocks (block b has sub (b + 1) tiles) -> the G workgroups of a (b,h).  method 0: longest first into the workgroup with the
+// fewest tiles so far (few blocks per workgroup, but the fullest ends up to a block above the mean when blocks are large
+// against a workgroup's share: T = 1024 on 21 workgroups, 109 tiles against a mean of 99); method 1: best fit decreasing into
+// workgroups of capacity C = the mean rounded up to the SIMDs' quantum, C + 4, ... (reaches the mean; the last workgroup
 // collects the small blocks).  A workgroup's blocks are then laid end to end, longest first, and cut into four runs of
-// q = ceil(load / 4) tiles, one per wave.
-static bool build(int n16, int G, int J, int method, Plan16 &out) {
+// q = ceil(load / 4) tiles, one per SIMD; with eight waves each run is halved between the SIMD's two waves.
+static bool build(int nblocks, int sub, int G, int waves, int method, double kv_mb, Plan16 &out) {
+    const int J = kWordsPerWg / waves;
     std::vector<std::vector<int>> bins;
     std::vector<int> load;
     if (method == 0) {
         bins.assign((size_t)G, {});
         load.assign((size_t)G, 0);
-        for (int t = n16; t >= 1; --t) {
+        for (int b = nblocks; b >= 1; --b) {
             int pick = 0;
             for (int j = 1; j < G; ++j) if (load[j] < load[pick]) pick = j;
-            bins[pick].push_back(t);
-            load[pick] += t;
+            bins[pick].push_back(b);
+            load[pick] += sub * b;
         }
     } else {
-        const int total = n16 * (n16 + 1) / 2;
-        int C = std::max(kWaves * ((total + kWaves * G - 1) / (kWaves * G)), kWaves * ((n16 + kWaves - 1) / kWaves));
-        for (;; C += kWaves) {
+        const int total = sub * nblocks * (nblocks + 1) / 2;
+        int C = std::max(4 * ((total + 4 * G - 1) / (4 * G)), 4 * ((sub * nblocks + 3) / 4));
+        for (;; C += 4) {
             bins.clear();
             load.clear();
             bool fits = true;
-            for (int t = n16; t >= 1 && fits; --t) {
+            for (int b = nblocks; b >= 1 && fits; --b) {
+                const int t = sub * b;
                 int pick = -1;
                 for (int j = 0; j < (int)bins.size(); ++j)
                     if (load[j] + t <= C && (pick < 0 || load[j] > load[pick])) pick = j;
@@ -497,7 +520,7 @@ static bool build(int n16, int G, int J, int method, Plan16 &out) {
                     load.push_back(0);
                     pick = (int)bins.size() - 1;
                 }
-                bins[pick].push_back(t);
+                bins[pick].push_back(b);
                 load[pick] += t;
             }
             if (fits) break;
@@ -508,57 +531,109 @@ static bool build(int n16, int G, int J, int method, Plan16 &out) {
     std::vector<int> order((size_t)G);
     for (int j = 0; j < G; ++j) order[j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return load[a] > load[b2]; });
-    out.n16 = n16;
+    out.sub = sub;
+    out.blocks = nblocks;
     out.wgs_per_bh = G;
-    out.jobs_per_wave = J;
-    out.tiles_per_wave = 0;
+    out.waves = waves;
+    out.tiles_per_simd = 0;
     out.max_jobs = 0;
     out.cycles = 0.0;
     std::fill(out.table, out.table + kTableWords, 0u);
     for (int jo = 0; jo < G; ++jo) {
-        const int j = order[jo], S = load[j], q = (S + kWaves - 1) / kWaves;
-        out.tiles_per_wave = std::max(out.tiles_per_wave, q);
-        int njobs[kWaves] = {0, 0, 0, 0};
+        const int j = order[jo], S = load[j], q = (S + 3) / 4;
+        out.tiles_per_simd = std::max(out.tiles_per_simd, q);
+        // list boundaries in run order: bound[u] .. bound[u + 1]
+        int bound[kMaxWaves + 1];
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int a = std::min(S, sidx * q), e = std::min(S, (sidx + 1) * q);
+            if (waves == 8) {
+                bound[2 * sidx] = a;
+                bound[2 * sidx + 1] = a + (e - a + 1) / 2;
+            } else {
+                bound[sidx] = a;
+            }
+        }
+        bound[waves] = S;
+        int njobs[kMaxWaves] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool merges = false;
         int pos = 0;
-        for (int t : bins[j]) {
-            const int w_first = pos / q, w_last = (pos + t - 1) / q, pieces = w_last - w_first + 1;
-            if (pieces > 4 || w_last >= kWaves) return false;
+        for (int b : bins[j]) {
+            const int t = sub * b;
+            // the lists [bound[u], bound[u+1]) that the block's tiles [pos, pos + t) meet
+            int u_first = -1, u_last = -1;
+            for (int uu = 0; uu < waves; ++uu)
+                if (std::max(pos, bound[uu]) < std::min(pos + t, bound[uu + 1])) { if (u_first < 0) u_first = uu; u_last = uu; }
+            if (u_first < 0) return false;
+            const int pieces = u_last - u_first + 1;
+            if (pieces > 8) return false;
             merges |= pieces > 1;
-            for (int w = w_first; w <= w_last; ++w) {
-                const int lo = std::max(pos, w * q), hi = std::min(pos + t, (w + 1) * q);
-                if (njobs[w] >= J) return false;
-                out.table[((size_t)jo * kWaves + w) * J + njobs[w]++] = job_word(t - 1, lo - pos, hi - lo, w - w_first, pieces);
+            for (int uu = u_first; uu <= u_last; ++uu) {
+                const int lo = std::max(pos, bound[uu]), hi = std::min(pos + t, bound[uu + 1]);
+                if (hi <= lo) return false;                                        // (an empty list inside a block's span: cannot happen)
+                if (njobs[uu] >= J) return false;
+                out.table[(size_t)jo * kWordsPerWg + uu * J + njobs[uu]++] = job_word(b - 1, lo - pos, hi - lo, uu - u_first, pieces);
             }
             pos += t;
         }
-        for (int w = 0; w < kWaves; ++w) {
-            out.max_jobs = std::max(out.max_jobs, njobs[w]);
-            const int tiles_w = std::max(0, std::min(S, (w + 1) * q) - w * q);
-            out.cycles = std::max(out.cycles, kFixedCycles + kTileCycles * tiles_w + kJobCycles * njobs[w]);
-            if (merges) out.table[((size_t)jo * kWaves + w) * J] |= kWgMergesBit;
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            int tiles_s = 0, jobs_s = 0;
+            for (int k2 = 0; k2 < waves / 4; ++k2) {
+                const int uu = waves == 8 ? 2 * sidx + k2 : sidx;
+                tiles_s += bound[uu + 1] - bound[uu];
+                jobs_s += njobs[uu];
+                out.max_jobs = std::max(out.max_jobs, njobs[uu]);
+            }
+            out.cycles = std::max(out.cycles, kFixedCycles + tiles_cost(sub, waves, tiles_s, kv_mb) + kJobCycles * sub * std::max(0, jobs_s - 1));
         }
+        if (merges)
+            for (int uu = 0; uu < waves; ++uu) out.table[(size_t)jo * kWordsPerWg + uu * J] |= kWgMergesBit;
     }
     return true;
 }
 
-bool make_plan(int64_t bh, int n16, int cus, Plan16 &out) {
+bool make_plan(int64_t bh, int seq_len, int cus, Plan16 &out, int force_sub, int force_waves, int force_contig) {
     out.ok = false;
-    if (n16 < 1 || n16 > kMaxBlocks || bh < 1 || bh > cus) return false;
-    const int g_cap = (int)std::min<int64_t>(cus / bh, n16);      // one workgroup per CU, one wave per SIMD; a block is never shared
+    if (seq_len < 1 || bh < 1 || bh > cus) return false;
     Plan16 best;
-    for (int J = 4; J <= 8; J += 4) {
-        const int G = std::min(g_cap, kTableWords / (kWaves * J));
+    for (int sub = 1; sub <= 2; ++sub) {
+        if (force_sub && force_sub != sub) continue;
+        const int nblocks = (seq_len + 16 * sub - 1) / (16 * sub);
+        if (sub * nblocks > kMaxTiles) continue;
+        // one workgroup per CU; a block is never shared between workgroups
+        const int G = (int)std::min<int64_t>(std::min<int64_t>(cus / bh, nblocks), kMaxWgs);
         if (G < 1) continue;
-        for (int method = 0; method < 2; ++method) {
-            Plan16 cand;
-            if (!build(n16, G, J, method, cand)) continue;
-            if (!best.ok || cand.cycles < best.cycles) { best = cand; best.ok = true; }
+        for (int waves = 4; waves <= 8; waves += 4) {
+            if (force_waves && force_waves != waves) continue;
+            for (int method = 0; method < 2; ++method) {
+                Plan16 cand;
+                if (!build(nblocks, sub, G, waves, method, (double)bh * seq_len * 512.0 / 1048576.0, cand)) continue;
+                if (!best.ok || cand.cycles < best.cycles) { best = cand; best.ok = true; }
+            }
         }
     }
     if (!best.ok) return false;
+    // short launches take the map that spares the prologue a dependent scalar load; long ones the XCD-contiguous map
+    best.contig = force_contig >= 0 ? force_contig != 0 : best.tiles_per_simd * best.sub >= 12;
     out = best;
     return true;
+}
+
+template <int kSub, int kWaves, bool kContig>
+static int launch_variant(const Params16 &p, int64_t bh, void *stream) {
+    static std::atomic<int> attr_set[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const void *fn = reinterpret_cast<const void *>(fwd16_kernel<kSub, kWaves, kContig>);
+    constexpr int kLds = lds_bytes(kSub, kWaves);
+    if (kLds > 65536 && (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire))) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(1, std::memory_order_release);
+    }
+    void *args[] = {const_cast<Params16 *>(&p)};
+    const dim3 grid = kContig ? dim3((unsigned)p.per_xcd * 8u) : dim3((unsigned)p.wgs_per_bh, (unsigned)bh);
+    return (int)hipLaunchKernel(fn, grid, dim3(kWaves * 64), args, kLds, static_cast<hipStream_t>(stream));
 }
 
 int launch(const Plan16 &plan, const float *q, const float *k, const float *v, float *o,
@@ -576,9 +651,17 @@ int launch(const Plan16 &plan, const float *q, const float *k, const float *v, f
     p.heads_magic = 0xffffffffu / (unsigned)num_heads;
     p.wgs_magic = 0xffffffffu / (unsigned)plan.wgs_per_bh;
     memcpy(p.table, plan.table, sizeof(p.table));
-    void *args[] = {&p};
-    const void *fn = plan.jobs_per_wave == 8 ? reinterpret_cast<const void *>(fwd16_kernel<8>) : reinterpret_cast<const void *>(fwd16_kernel<4>);
-    return (int)hipLaunchKernel(fn, dim3((unsigned)p.per_xcd * 8u), dim3(kWaves * 64), args, 0, static_cast<hipStream_t>(stream));
+    const int key = (plan.sub == 2 ? 4 : 0) | (plan.waves == 8 ? 2 : 0) | (plan.contig ? 1 : 0);
+    switch (key) {
+        case 0: return launch_variant<1, 4, false>(p, bh, stream);
+        case 1: return launch_variant<1, 4, true>(p, bh, stream);
+        case 2: return launch_variant<1, 8, false>(p, bh, stream);
+        case 3: return launch_variant<1, 8, true>(p, bh, stream);
+        case 4: return launch_variant<2, 4, false>(p, bh, stream);
+        case 5: return launch_variant<2, 4, true>(p, bh, stream);
+        case 6: return launch_variant<2, 8, false>(p, bh, stream);
+        default: return launch_variant<2, 8, true>(p, bh, stream);
+    }
 }
 
 #ifdef CMHSA_STAMPS

@@ -539,16 +539,17 @@ Plan choose_plan(int64_t bh, int nqb, int seq_len_hint, int cus, bool allow_spli
     //       Grids of one round (bh <= CUs, T <= 4080): a quarter of the 32 x 32 unit's quantum and half its fixed cost.
     {
         static const int forced_t16 = env_int("CMHSA_T16", -1);      // -1 = planner's choice, 0 = never, 1 = wherever it applies
-        const int n16 = (seq_len_hint + 15) / 16;
+        static const int forced_sub = env_int("CMHSA_T16_SUB", 0), forced_w16 = env_int("CMHSA_T16_WAVES", 0), forced_contig = env_int("CMHSA_T16_CONTIG", -1);
         Plan t;
-        if (forced_t16 != 0 && !forced_old && !forced_packed && forced_waves != 1 && cmhsa_t16::make_plan(bh, n16, cus, t.t16) &&
+        if (forced_t16 != 0 && !forced_old && !forced_packed && forced_waves != 1 &&
+            cmhsa_t16::make_plan(bh, seq_len_hint, cus, t.t16, forced_sub, forced_w16, forced_contig) &&
             (forced_t16 == 1 || !have || t.t16.cycles < best.cycles * 0.97)) {
             t.tiles16 = true;
-            t.pp = pack_plan(nqb, cmhsa_t16::kWaves);
+            t.pp = pack_plan(nqb, t.t16.waves);
             t.pp.wgs_per_bh = t.n_wgs = t.t16.wgs_per_bh;
             t.single_round = true;
             t.cycles = t.t16.cycles;
-            t.family = "16-row blocks, job lists";
+            t.family = t.t16.sub == 2 ? "16-key tiles, 32-row blocks, job lists" : "16-key tiles, 16-row blocks, job lists";
             best = t;
             have = true;
         }

@@ -405,7 +405,14 @@ def test_long_sequences_spot_rows_against_f64(gpu_device, T, H):
 @pytest.mark.parametrize("env", [{"CMHSA_TABLE": "1", "CMHSA_WAVES": "8"}, {"CMHSA_TABLE": "1", "CMHSA_WAVES": "4"},
                                  {"CMHSA_TABLE": "1", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "9"},
                                  {"CMHSA_TABLE": "0", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "7"},
-                                 {"CMHSA_WAVES": "1"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "16"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "1000000"}])
+                                 {"CMHSA_WAVES": "1"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "16"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "1000000"},
+                                 # the 16-key-tile family (csrc/cmhsa_fwd16.hip) wherever it fits, in each of its shapes: 16- / 32-row
+                                 # blocks, one / two waves per SIMD, both workgroup -> (b,h) maps; and switched off altogether
+                                 {"CMHSA_T16": "1", "CMHSA_T16_SUB": "1", "CMHSA_T16_WAVES": "4"},
+                                 {"CMHSA_T16": "1", "CMHSA_T16_SUB": "1", "CMHSA_T16_WAVES": "8", "CMHSA_T16_CONTIG": "1"},
+                                 {"CMHSA_T16": "1", "CMHSA_T16_SUB": "2", "CMHSA_T16_WAVES": "4", "CMHSA_T16_CONTIG": "0"},
+                                 {"CMHSA_T16": "1", "CMHSA_T16_SUB": "2", "CMHSA_T16_WAVES": "8"},
+                                 {"CMHSA_T16": "0"}])
 def test_forced_plans_in_a_child_process(env):
     """The plan (workgroup shape, chain cap, analytic or table packing with up to four query blocks per workgroup) is
     chosen per shape by a cost model.  The shipped library reads no environment variable; the TEST build of the same
@@ -425,22 +432,32 @@ cmhsa.LIB_PATH = %r          # the plan-forcing test build of the same kernel so
 from oracle import naive_attention as oracle
 rng = np.random.default_rng(77)
 worst = 0.0
-for B, T, H in ((1, 1, 1), (1, 31, 2), (1, 33, 3), (2, 257, 4), (1, 1000, 5), (1, 1024, 20), (3, 700, 12), (1, 2049, 2), (1, 8100, 1)):
+for B, T, H in ((1, 1, 1), (1, 16, 12), (1, 17, 12), (1, 31, 2), (1, 33, 3), (1, 100, 25), (2, 257, 4), (1, 500, 12), (1, 1000, 5), (1, 1024, 20),
+                (3, 700, 12), (1, 2049, 2), (1, 4064, 3), (1, 8100, 1)):
     qkv = rng.standard_normal((B, T, 3 * 64 * H), dtype=np.float32)
+    if T > 64:
+        qkv[:, T // 2:, 64 * H:2 * 64 * H] *= 4.0          # later keys score higher: the running max moves inside and across jobs
     t = torch.from_numpy(qkv).cuda()
     d = 64 * H
-    out = cmhsa.attention_fwd(t[..., :d], t[..., d:2 * d], t[..., 2 * d:], H).cpu().numpy()
+    out = torch.full((B, T, d), float("nan"), device="cuda")
+    cmhsa.attention_fwd(t[..., :d], t[..., d:2 * d], t[..., 2 * d:], H, out=out)
+    out = out.cpu().numpy()
+    assert np.isfinite(out).all(), (B, T, H)              # every element written
     for b in range(B):
         for h in sorted({0, H - 1}):
             sl = slice(64 * h, 64 * h + 64)
             want = oracle.naive_attention_f64(qkv[b, :, sl], qkv[b, :, d + 64 * h:d + 64 * h + 64], qkv[b, :, 2 * d + 64 * h:2 * d + 64 * h + 64], 1)
             worst = max(worst, float(np.abs(out[b, :, sl] - want).max()))
-print("WORST", worst)
+print("WORST", worst, cmhsa.plan_description(1, 500, 12))
 assert worst <= 1e-4
 """ % (root, os.path.join(root, "llm-inference_amd"), os.path.join(root, "tests", "helpers", "libcmhsa_hip_planenv.so"))
     r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "WORST" in r.stdout
+    if "CMHSA_T16" in env:                                # the forced family really ran (B=1, T=500, H=12 fits it)
+        assert ("16-key tiles" in r.stdout) == (env["CMHSA_T16"] == "1"), r.stdout[-500:]
+        if env["CMHSA_T16"] == "1":
+            assert ("%s-row blocks" % (16 * int(env["CMHSA_T16_SUB"]))) in r.stdout and ("%s-wave" % env["CMHSA_T16_WAVES"]) in r.stdout, r.stdout[-500:]
 
 
 def test_random_shapes_fuzz(gpu_device):

@@ -52,7 +52,10 @@ def test_idle_waves_do_not_read_leftover_lds(pattern, gpu_device):
 
 
 @pytest.mark.parametrize("env", [{"CMHSA_TABLE": "1", "CMHSA_WAVES": "8"}, {"CMHSA_TABLE": "1", "CMHSA_WAVES": "4"},
-                                 {"CMHSA_TABLE": "0", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "7"}, {"CMHSA_WAVES": "1"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "16"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "1000000"}])
+                                 {"CMHSA_TABLE": "0", "CMHSA_WAVES": "8", "CMHSA_CHAIN": "7"}, {"CMHSA_WAVES": "1"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "16"}, {"CMHSA_WAVES": "1", "CMHSA_LPT": "1000000"},
+                                 # the 16-key-tile family: waves with empty job lists, LDS slots that no piece was stored to
+                                 {"CMHSA_T16": "1", "CMHSA_T16_SUB": "1", "CMHSA_T16_WAVES": "4"}, {"CMHSA_T16": "1", "CMHSA_T16_SUB": "1", "CMHSA_T16_WAVES": "8"},
+                                 {"CMHSA_T16": "1", "CMHSA_T16_SUB": "2", "CMHSA_T16_WAVES": "4"}, {"CMHSA_T16": "1", "CMHSA_T16_SUB": "2", "CMHSA_T16_WAVES": "8"}])
 def test_forced_plans_with_poisoned_lds_in_a_child_process(env):
     """The same check under forced table / analytic plans (spare waves in table plans), through the plan-forcing test
     build of the kernel sources (tests/helpers/libcmhsa_hip_planenv.so)."""

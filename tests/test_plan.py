@@ -27,9 +27,64 @@ import cmhsa  # noqa: E402
 WORKSPACE_BYTES = 16384 + 1024 * (2048 + 64) * 4          # CMHSA_WORKSPACE_BYTES (include/cmhsa.h)
 
 
+def check_tiles16_plan(plan, B, T, H, cus):
+    """The 16-key-tile family (csrc/cmhsa_tiles16.h): per workgroup 4 or 8 job lists in run order; a job = a run of key tiles
+    of one query block of 16 * sub rows.  Every tile [0, sub * (b + 1)) of every block b exactly once; the pieces of a cut
+    block on consecutive lists of ONE workgroup with ranks 0, 1, ... in key order; per list at most one piece that starts
+    its block and one later piece (the two LDS slots); the barrier flag on every list of a workgroup that cuts a block, on
+    none otherwise; lists packed at the front; one workgroup per CU."""
+    tag = (B, T, H, cus)
+    sub, W, J = plan["sub"], plan["waves"], plan["jobs_per_wave"]
+    nblocks = (T + 16 * sub - 1) // (16 * sub)
+    assert sub in (1, 2) and W in (4, 8) and J == 32 // W and plan["blocks"] == nblocks, tag
+    assert 1 <= plan["wgs_per_bh"] <= 28 and B * H * plan["wgs_per_bh"] <= cus, tag
+    assert sub * nblocks <= 255, tag
+    if plan["contig"]:
+        assert plan["grid_x"] % 8 == 0 and plan["grid_x"] >= B * H * plan["wgs_per_bh"] and plan["grid_y"] == 1, tag
+    else:
+        assert plan["grid_x"] == plan["wgs_per_bh"] and plan["grid_y"] == B * H, tag
+    cov = {b: [] for b in range(nblocks)}
+    for j, wg in enumerate(plan["workgroups"]):
+        assert len(wg) == W, tag
+        any_cut = False
+        for u, jobs in enumerate(wg):
+            assert len(jobs) <= J, (tag, j, u)
+            tiles = sum(c for _, _, c, _, _ in jobs)
+            if W == 8 and u % 2 == 0:
+                tiles += sum(c for _, _, c, _, _ in wg[u + 1])
+            if W == 4 or u % 2 == 0:
+                assert tiles <= plan["tiles_per_simd"], (tag, j, u)
+            later = first = 0
+            for blk, lo, cnt, rank, pieces in jobs:
+                assert 0 <= blk < nblocks and cnt >= 1 and lo + cnt <= sub * (blk + 1), (tag, j, u, blk, lo, cnt)
+                assert 1 <= pieces <= W and rank < pieces, (tag, j, u)
+                cov[blk].append((lo, cnt, rank, pieces, j, u))
+                if pieces > 1:
+                    any_cut = True
+                    later += rank > 0
+                    first += rank == 0
+            assert later <= 1 and first <= 1, (tag, j, u)
+        assert all(m == any_cut for m in plan["merges"][j]), (tag, j)
+        for words in plan["raw_words"][j]:
+            counts = [(x >> 16) & 255 for x in words]
+            assert counts == sorted(counts, key=lambda c: c == 0), (tag, j)      # no job behind an empty word
+    for blk, ps in cov.items():
+        ps.sort()
+        end = 0
+        for k, (lo, cnt, rank, pieces, j, u) in enumerate(ps):
+            assert lo == end and rank == k and pieces == len(ps), (tag, blk, ps)
+            assert j == ps[0][4] and u == ps[0][5] + k, (tag, blk, ps)
+            end = lo + cnt
+        assert end == sub * (blk + 1), (tag, blk, ps)
+    return plan
+
+
 def check_plan(B, T, H, with_ws, cus):
     plan = cmhsa.plan_dump(B, T, H, with_ws, cus)
     tag = (B, T, H, with_ws, cus)
+    if plan["family"] == "tiles16":
+        assert plan["workspace_256"] == 0 and plan["parts_per_bh"] == 0, tag
+        return check_tiles16_plan(plan, B, T, H, cus)
     nqb = (T + 31) // 32
     bh = B * H
     waves = plan["waves"]
@@ -118,11 +173,16 @@ def test_every_plan_covers_every_unit_once(with_ws):
         if B * H * T > 64 * 25 * 1024:
             continue
         plan = check_plan(B, T, H, with_ws, 256)
-        families.add((plan["waves"], plan["use_table"], bool(plan["longest_first"]), bool(plan["parts_per_bh"])))
         count += 1
+        if plan["family"] == "tiles16":
+            families.add("tiles16")
+            continue
+        families.add((plan["waves"], plan["use_table"], bool(plan["longest_first"]), bool(plan["parts_per_bh"])))
     assert count > 400
     # the sweep reaches every family: analytic 4 / 8 waves, tables, split tables (with a workspace), both one-wave forms
     assert {(4, 0, False, False), (8, 0, False, False), (1, 0, False, False), (1, 0, True, False)} <= families
+    assert "tiles16" in families
+    families.discard("tiles16")
     assert any(t for _, t, _, _ in families)
     if with_ws:
         assert any(p for _, _, _, p in families)
@@ -142,7 +202,36 @@ def test_long_sequences_and_large_batches():
             check_plan(B, T, H, with_ws, 256)
 
 
+@pytest.mark.parametrize("env", [{"CMHSA_T16_SUB": "1", "CMHSA_T16_WAVES": "4"}, {"CMHSA_T16_SUB": "1", "CMHSA_T16_WAVES": "8"},
+                                 {"CMHSA_T16_SUB": "2", "CMHSA_T16_WAVES": "4"}, {"CMHSA_T16_SUB": "2", "CMHSA_T16_WAVES": "8"}])
+def test_forced_tiles16_plans_cover_every_tile_once(env):
+    """The planner picks the 16-key-tile family only where it prices best; the plan-forcing TEST build of the library
+    (tests/helpers/libcmhsa_hip_planenv.so, CMHSA_T16=1) applies it wherever it fits, in each of its four shapes."""
+    import subprocess
+
+    code = r"""
+import sys, itertools
+sys.path[:0] = [%r, %r]
+import cmhsa
+cmhsa.LIB_PATH = %r
+import test_plan
+n = 0
+for B, H, T in itertools.product((1, 2, 3, 5, 8, 16), (1, 3, 12, 16, 25), (1, 15, 16, 17, 31, 33, 64, 100, 255, 256, 500, 512, 777, 1000, 1024, 1536, 2048, 4000, 4064)):
+    for cus in (256, 104):
+        plan = cmhsa.plan_dump(B, T, H, False, cus)
+        if plan["family"] == "tiles16":
+            test_plan.check_tiles16_plan(plan, B, T, H, cus)
+            n += 1
+print("CHECKED", n)
+assert n > 300
+""" % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "llm-inference_amd"), os.path.join(ROOT, "tests", "helpers", "libcmhsa_hip_planenv.so"))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "CMHSA_T16": "1", **env}, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_baseline_configs_pick_the_documented_families():
+    small = cmhsa.plan_dump(1, 256, 12, True, 256)                 # the B = 1 launches of a generation (config 3)
+    assert small["family"] == "tiles16" and small["sub"] == 1 and small["waves"] == 4
     c2 = cmhsa.plan_dump(1, 1024, 12, True, 256)
     assert c2["waves"] == 8 and c2["use_table"] and c2["splits_per_bh"] >= 1 and c2["simd_cap"] == 7 and c2["wgs_per_bh"] == 21
     c2_plain = cmhsa.plan_dump(1, 1024, 12, False, 256)
