@@ -31,8 +31,8 @@ int gpt2_embed_f32_fwd(const int64_t *tokens, int64_t tokens_row_stride, const f
 
 /* logits: (batch, vocab) fp32, row stride logits_row_stride (floats); done: `batch` bytes (bool); tokens: int64 rows of
  * tokens_row_stride elements with capacity `cap`; pos: ONE int64 on the device = index of the last valid token (the
- * kernel writes column pos + 1 and leaves pos alone: increment it afterwards, in stream order).  NaN logits never win
- * (as torch.argmax treats them, a row of NaNs excepted, which picks index 0 here).  pos + 1 >= cap writes nothing.
+ * kernel writes column pos + 1 and leaves pos alone: increment it afterwards, in stream order).  The first maximum wins and NaN
+ * ranks above every number -- exactly torch.argmax, which the reference's sampler calls.  pos + 1 >= cap writes nothing.
  * Returns as above.                                                                          [sampler.py:14-19] */
 int gpt2_greedy_step(const float *logits, int64_t logits_row_stride, unsigned char *done, int64_t *tokens,
                      int64_t tokens_row_stride, const int64_t *pos, int batch, int vocab, int cap, int64_t eos, void *stream);

@@ -29,12 +29,20 @@ _EXTENSION_MODULE = "causal_multihead_self_attention"
 
 
 class ScaledDotProductAttentionBackend(Enum):
-    # Two members only.  The reference's PYTORCH_SDPA_* members (reference :8-11) select stock PyTorch kernels and its
-    # CUSTOM_CUDA_VERSION_1..12 members frozen CUDA snapshots: neither is part of this path, and this build has no
-    # multi-backend dispatch -- the custom kernel plus the naive formula it is checked against on the same device.
+    # The custom kernel, the naive formula it is checked against on the same device, and -- so that callers written for
+    # the reference (plot_inference_times.py:11, :45) keep working -- the reference's PYTORCH_SDPA_* members (reference
+    # :8-11), which select STOCK PyTorch kernels: a second on-device comparator, nothing of this build's.  The reference's
+    # CUSTOM_CUDA_VERSION_1..12 members name frozen CUDA snapshots that are not part of this path and have no member here.
     NAIVE_PYTORCH = "NAIVE_PYTORCH"
     CUSTOM_CUDA = "CUSTOM_CUDA"
     CUSTOM_HIP = "CUSTOM_CUDA"      # alias of CUSTOM_CUDA (same value => same member)
+    PYTORCH_SDPA_MATH = "PYTORCH_SDPA_MATH"
+    PYTORCH_SDPA_FLASH_ATTENTION = "PYTORCH_SDPA_FLASH_ATTENTION"
+    PYTORCH_SDPA_EFFICIENT_ATTENTION = "PYTORCH_SDPA_EFFICIENT_ATTENTION"
+    PYTORCH_SDPA_CUDNN_ATTENTION = "PYTORCH_SDPA_CUDNN_ATTENTION"
+
+
+PYTORCH_SDPA_BACKENDS = [b for b in ScaledDotProductAttentionBackend if b.name.startswith("PYTORCH_SDPA_")]      # reference :28-31
 
 
 def load_attention_backend(backend: ScaledDotProductAttentionBackend) -> None:
@@ -92,6 +100,14 @@ def scaled_dot_product_attention(backend: ScaledDotProductAttentionBackend,
                                                           num_heads=num_heads, causal_mask=causal_mask)
     if backend is ScaledDotProductAttentionBackend.CUSTOM_CUDA:
         return _custom_attention(queries, keys, values, num_heads)
+    if backend in PYTORCH_SDPA_BACKENDS:
+        # torch.nn.functional.scaled_dot_product_attention restricted to one of torch's own kernels (reference :113-119,
+        # :127-142); whether a kernel exists for fp32 on this device is torch's business (it raises if none does)
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+
+        q, k, v = (_split_heads(t, num_heads) for t in (queries, keys, values))
+        with sdpa_kernel(getattr(SDPBackend, backend.name[len("PYTORCH_SDPA_"):])):
+            return _merge_heads(torch.nn.functional.scaled_dot_product_attention(query=q, key=k, value=v, is_causal=True))
     raise ValueError("Backend not implemented yet")
 
 

@@ -28,9 +28,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t *tokens, int64
 
 constexpr int kPickThreads = 1024;
 
-// strictly greater wins, equal keeps the smaller index: the first maximum, as torch.argmax
+// strictly greater wins, equal keeps the smaller index: the first maximum, as torch.argmax (reference sampler.py:17) --
+// which ranks NaN above every number, so the first NaN of a row wins
 __device__ __forceinline__ void better(float &bv, int &bi, float v, int i) {
-    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    const bool vn = v != v, bn = bv != bv;
+    const bool gt = vn ? !bn : (!bn && v > bv), eq = vn ? bn : (!bn && v == bv);
+    if (gt || (eq && i < bi)) { bv = v; bi = i; }
 }
 
 // one workgroup per batch row
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(kPickThreads) void greedy_step_kernel(const float *
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < kPickThreads / 64; ++w) better(bv, bi, sv[w], si[w]);
-        if (bi == 0x7fffffff) bi = 0;                           // every logit NaN (or -inf everywhere past index order)
+        if (bi == 0x7fffffff) bi = 0;                           // (not reached: -inf equals the initial value and takes its index)
         int64_t next = done[b] ? eos : (int64_t)bi;
         if (next == eos) done[b] = 1;
         const int64_t col = pos[0] + 1;

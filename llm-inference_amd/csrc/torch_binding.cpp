@@ -47,24 +47,76 @@ static void check_one(const at::Tensor &t, const char *name, int64_t dim) {
 }
 
 // Workspace of cmhsa_fp32_fwd_ws (query blocks split across workgroups), one per (device, stream): calls on one stream
-// are ordered, calls on different streams must not share it.  Allocated and zeroed at a stream's first call; a first
-// call that arrives while the stream is being captured into a graph gets none (no allocation, no memset node in a
-// capture) and runs the plan that needs no workspace.  The tensors live until the process ends.
-static void *stream_workspace(int device, hipStream_t stream, size_t *bytes) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, at::Tensor> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find({device, stream});
-    if (it == cache.end()) {
-        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &status) != hipSuccess || status != hipStreamCaptureStatusNone) { *bytes = 0; return nullptr; }
-        at::Tensor ws = at::empty({(int64_t)cmhsa_workspace_bytes()}, at::TensorOptions().dtype(at::kByte).device(at::kCUDA, device));
+// are ordered, calls on different streams must not share it.
+//   * Sized by need: cmhsa_fp32_fwd_workspace_bytes(shape) rounded up to 256 KiB, grown when a larger shape arrives (most
+//     shapes need none: no entry is made for them).  At most kMaxEntries (device, stream) pairs are kept; beyond that the
+//     least recently used one that no graph capture has seen is dropped.
+//   * Under graph capture nothing is allocated and nothing is memset: a capturing call uses its stream's workspace if
+//     one of sufficient size exists ALREADY -- made by an earlier eager call on that stream, e.g. the warm-up step that
+//     torch's capture recipe runs first, or by reserve_workspace() -- and otherwise the plan that needs none (the same
+//     function, another summation order: results within rounding of each other, bitwise reproducible either way).
+//   * A captured graph has the workspace's address baked in and owns it from then on: such an entry is never dropped or
+//     replaced in place (a larger one is added beside it and the old buffer kept alive), and two graphs captured on one
+//     stream must not be replayed concurrently on different streams -- they share that stream's workspace.
+namespace {
+struct WorkspaceEntry {
+    at::Tensor buf;
+    bool seen_by_capture = false;
+    uint64_t last_use = 0;
+};
+constexpr size_t kMaxEntries = 16;
+constexpr size_t kWorkspaceGranule = 256 * 1024;
+std::mutex g_ws_mu;
+std::map<std::pair<int, hipStream_t>, WorkspaceEntry> g_ws_cache;
+std::vector<at::Tensor> g_ws_retired;            // outgrown buffers that a captured graph may still point at
+uint64_t g_ws_tick = 0;
+}  // namespace
+
+static void *stream_workspace(int device, hipStream_t stream, size_t need, size_t *bytes) {
+    *bytes = 0;
+    if (need == 0) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &status) != hipSuccess || status != hipStreamCaptureStatusNone;
+    auto it = g_ws_cache.find({device, stream});
+    const bool have = it != g_ws_cache.end() && (size_t)it->second.buf.numel() >= need;
+    if (!have) {
+        if (capturing) return nullptr;               // no allocation, no memset node in a capture
+        const size_t size = (need + kWorkspaceGranule - 1) / kWorkspaceGranule * kWorkspaceGranule;
+        at::Tensor ws = at::empty({(int64_t)size}, at::TensorOptions().dtype(at::kByte).device(at::kCUDA, device));
         const int rc = cmhsa_workspace_init(ws.data_ptr(), (size_t)ws.numel(), stream);
         TORCH_CHECK(rc == CMHSA_OK, "cmhsa_workspace_init failed (", rc, "): ", cmhsa_status_string(rc));
-        it = cache.emplace(std::make_pair(device, stream), ws).first;
+        if (it != g_ws_cache.end()) {
+            if (it->second.seen_by_capture) g_ws_retired.push_back(it->second.buf);
+            it->second.buf = ws;
+        } else {
+            if (g_ws_cache.size() >= kMaxEntries) {
+                auto victim = g_ws_cache.end();
+                for (auto e = g_ws_cache.begin(); e != g_ws_cache.end(); ++e)
+                    if (!e->second.seen_by_capture && (victim == g_ws_cache.end() || e->second.last_use < victim->second.last_use)) victim = e;
+                if (victim != g_ws_cache.end()) g_ws_cache.erase(victim);      // (its stream's queued launches keep the memory: torch frees stream-ordered)
+            }
+            it = g_ws_cache.emplace(std::make_pair(device, stream), WorkspaceEntry{ws, false, 0}).first;
+        }
     }
-    *bytes = (size_t)it->second.numel();
-    return it->second.data_ptr();
+    it->second.seen_by_capture |= capturing;
+    it->second.last_use = ++g_ws_tick;
+    *bytes = (size_t)it->second.buf.numel();
+    return it->second.buf.data_ptr();
+}
+
+// Makes sure that the CURRENT stream of `like`'s device has a workspace large enough for this shape (outside capture), so
+// that a capture on that stream later runs the plans that split query blocks.  Returns the bytes the shape needs (0: none).
+int64_t reserve_workspace(at::Tensor like, int64_t batch, int64_t seq_len, int64_t num_heads) {
+    TORCH_CHECK(like.is_cuda(), "like must be a CUDA tensor (it names the device)");
+    TORCH_CHECK(batch >= 0 && seq_len >= 0 && num_heads > 0 && batch <= INT32_MAX && seq_len <= INT32_MAX && num_heads <= INT32_MAX, "bad shape");
+    const c10::hip::HIPGuard guard(like.device().index());
+    const hipStream_t stream = c10::hip::getCurrentHIPStream(like.device().index()).stream();
+    const size_t need = cmhsa_fp32_fwd_workspace_bytes((int)batch, (int)seq_len, (int)num_heads);
+    size_t got = 0;
+    stream_workspace(like.device().index(), stream, need, &got);
+    TORCH_CHECK(got >= need, "reserve_workspace must be called outside graph capture");
+    return (int64_t)need;
 }
 
 at::Tensor causal_multihead_self_attention_torch(at::Tensor Q, at::Tensor K, at::Tensor V, int64_t num_heads) {
@@ -95,7 +147,7 @@ at::Tensor causal_multihead_self_attention_torch(at::Tensor Q, at::Tensor K, at:
     const hipStream_t stream = c10::hip::getCurrentHIPStream(Q.device().index()).stream();
     auto bs = [&](const at::Tensor &t) -> int64_t { return dim == 3 ? t.stride(0) : 0; };
     size_t ws_bytes = 0;
-    void *ws = cmhsa_fp32_fwd_workspace_bytes((int)B, (int)N, (int)num_heads) ? stream_workspace(Q.device().index(), stream, &ws_bytes) : nullptr;
+    void *ws = stream_workspace(Q.device().index(), stream, cmhsa_fp32_fwd_workspace_bytes((int)B, (int)N, (int)num_heads), &ws_bytes);
     const int rc = cmhsa_fp32_fwd_ws(Q.data_ptr<float>(), K.data_ptr<float>(), V.data_ptr<float>(), output.data_ptr<float>(),
                                      Q.stride(dim - 2), K.stride(dim - 2), V.stride(dim - 2), output.stride(dim - 2),
                                      bs(Q), bs(K), bs(V), bs(output),
@@ -123,7 +175,7 @@ at::Tensor causal_multihead_self_attention_packed_qkv(at::Tensor QKV, int64_t nu
     const c10::hip::HIPGuard guard(QKV.device().index());
     const hipStream_t stream = c10::hip::getCurrentHIPStream(QKV.device().index()).stream();
     size_t ws_bytes = 0;
-    void *ws = cmhsa_fp32_fwd_workspace_bytes((int)B, (int)N, (int)num_heads) ? stream_workspace(QKV.device().index(), stream, &ws_bytes) : nullptr;
+    void *ws = stream_workspace(QKV.device().index(), stream, cmhsa_fp32_fwd_workspace_bytes((int)B, (int)N, (int)num_heads), &ws_bytes);
     const int rc = cmhsa_fp32_fwd_packed_qkv(QKV.data_ptr<float>(), output.data_ptr<float>(), QKV.stride(dim - 2), output.stride(dim - 2),
                                              dim == 3 ? QKV.stride(0) : 0, dim == 3 ? output.stride(0) : 0,
                                              (int)B, (int)N, (int)num_heads, 64, ws, ws_bytes, stream);
@@ -317,6 +369,7 @@ void greedy_step(at::Tensor logits, at::Tensor done, at::Tensor tokens, at::Tens
 TORCH_LIBRARY(causal_multihead_self_attention, m) {
     m.def("causal_multihead_self_attention_torch(Tensor Q, Tensor K, Tensor V, int num_heads) -> Tensor");
     m.def("causal_multihead_self_attention_packed_qkv(Tensor QKV, int num_heads) -> Tensor");
+    m.def("reserve_workspace(Tensor like, int batch, int seq_len, int num_heads) -> int");
     m.def("causal_multihead_self_attention_decode(Tensor qkv_new, Tensor(a!) k_cache, Tensor(b!) v_cache, Tensor pos, int num_heads) -> Tensor");
     m.def("gelu_tanh(Tensor x) -> Tensor");
     m.def("add_layer_norm(Tensor x, Tensor? delta, Tensor weight, Tensor bias, float eps) -> (Tensor, Tensor)");
@@ -329,6 +382,7 @@ TORCH_LIBRARY(causal_multihead_self_attention, m) {
 TORCH_LIBRARY_IMPL(causal_multihead_self_attention, CUDA, m) {
     m.impl("causal_multihead_self_attention_torch", &causal_multihead_self_attention_torch);
     m.impl("causal_multihead_self_attention_packed_qkv", &causal_multihead_self_attention_packed_qkv);
+    m.impl("reserve_workspace", &reserve_workspace);
     m.impl("causal_multihead_self_attention_decode", &causal_multihead_self_attention_decode);
     m.impl("gelu_tanh", &gelu_tanh);
     m.impl("add_layer_norm", &add_layer_norm);

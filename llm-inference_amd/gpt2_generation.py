@@ -266,6 +266,7 @@ class BucketedGreedyGenerator:
         self.pos = torch.zeros((1,), dtype=torch.long, device=self.device)     # index of the last valid token
         self.done = torch.zeros((batch,), dtype=torch.bool, device=self.device)
         self._graphs: dict[int, "torch.cuda.CUDAGraph"] = {}
+        self._capture_stream = None
         self._pool = None
 
     def bucket_len(self, length: int) -> int:
@@ -299,13 +300,18 @@ class BucketedGreedyGenerator:
         g = self._graphs.get(L)
         if g is None:
             saved = (self.tokens.clone(), self.pos.clone(), self.done.clone())
-            side = torch.cuda.Stream(self.device)                     # warm-up off the capture stream: lazy inits,
-            side.wait_stream(torch.cuda.current_stream(self.device))  # GEMM workspace, LDS attribute of the kernel
+            # Warm-up ON the capture stream (one stream for every bucket of this generator): lazy inits, GEMM workspace,
+            # the kernel's LDS attribute -- and the attention op's per-stream workspace, which a capturing call can use
+            # but not create, so that captured and eager steps run the same plans.
+            if self._capture_stream is None:
+                self._capture_stream = torch.cuda.Stream(self.device)
+            side = self._capture_stream
+            side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 self._step(L)
             torch.cuda.current_stream(self.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._pool):                # one memory pool: the graphs never overlap
+            with torch.cuda.graph(g, pool=self._pool, stream=side):   # one memory pool: the graphs never overlap
                 self._step(L)
             if self._pool is None:
                 self._pool = g.pool()
@@ -499,7 +505,7 @@ class KVCacheGreedyGenerator:
             self._step()                                   # warm-up: lazy initialisations must not land in the capture
         torch.cuda.current_stream(self.device).wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, stream=side):   # captured on the stream that ran the warm-up
             self._step()
         for dst, src in zip((self.tokens, self.pos64, self.pos32, self.done), saved):
             dst.copy_(src)                                 # undo the warm-up step (its cache row is rewritten by the real one)

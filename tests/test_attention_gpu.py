@@ -259,6 +259,32 @@ def test_full_size_properties_config5_shape(gpu_device):
         assert np.abs(o1[b, :, sl].cpu().numpy() - want).max() <= TOL
 
 
+@pytest.mark.parametrize("B,H", [(32, 2), (32, 16)])
+def test_config5_literal_shapes(B, H, gpu_device):
+    """BASELINE.json configs[4] at its literal sizes: one GPU's head shard (B=32, H=2, T=4096: a column slab of Q, K, V with the
+    whole model's row stride, 3 * 1024 floats) and the whole config on one GPU (B=32, H=16: the N = 1 point).  Every
+    element written (NaN-filled output), the call bit-reproducible, with the workspace and without it, and sampled
+    (batch, head) pairs against the f64 oracle."""
+    torch.manual_seed(500 + H)
+    T, d_model = 4096, 1024
+    d = 64 * H
+    qkv = torch.randn(B, T, 3 * d_model, device=gpu_device)          # the model-wide packed activation
+    q, k, v = (qkv[..., i * d_model:i * d_model + d] for i in range(3))   # this GPU's heads: the first H of 16
+    assert q.stride() == (T * 3 * d_model, 3 * d_model, 1)
+    out = torch.full((B, T, d), float("nan"), device=gpu_device)
+    cmhsa.attention_fwd(q, k, v, H, out=out, workspace=cmhsa.Workspace(gpu_device))
+    assert torch.isfinite(out).all()
+    again = cmhsa.attention_fwd(q, k, v, H, workspace=cmhsa.Workspace(gpu_device))
+    assert torch.equal(out, again)
+    plain = cmhsa.attention_fwd(q, k, v, H)
+    assert torch.equal(out, plain)                                  # grids of many rounds: one plan with or without a workspace
+    for b, h in ((0, 0), (B - 1, H - 1), (B // 2, H // 2)):
+        sl = slice(64 * h, 64 * h + 64)
+        want = oracle.naive_attention_f64(q[b, :, sl].cpu().numpy(), k[b, :, sl].cpu().numpy(), v[b, :, sl].cpu().numpy(), 1)
+        assert np.abs(out[b, :, sl].cpu().numpy() - want).max() <= TOL, (b, h)
+    assert torch.allclose(out[:, 0], v[:, 0], atol=1e-6)            # row 0 attends to key 0 only
+
+
 @pytest.mark.parametrize("name", [n for n, c in cases.ATTENTION_CASES.items() if c["layout"] == "qkv"])
 def test_packed_qkv_entry_point_against_reference_goldens(name, gpu_device):
     """SURVEY 8(f) row 2 / VERDICT f2: the `layout="qkv"` goldens are exactly the packed (T, 3*d_model) buffer the

@@ -52,6 +52,23 @@ def test_enum_names_and_alias():
     assert ScaledDotProductAttentionBackend["NAIVE_PYTORCH"] is NAIVE
 
 
+def test_reference_sdpa_members_exist_and_dispatch_to_stock_torch():
+    """Callers written for the reference name PYTORCH_SDPA_* (reference causal_self_attention.py:8-11, :28-31,
+    plot_inference_times.py:11): the members exist and select torch's own kernels -- here the MATH one on the CPU,
+    against the naive formula."""
+    from causal_self_attention import PYTORCH_SDPA_BACKENDS
+
+    assert [b.name for b in PYTORCH_SDPA_BACKENDS] == ["PYTORCH_SDPA_MATH", "PYTORCH_SDPA_FLASH_ATTENTION",
+                                                       "PYTORCH_SDPA_EFFICIENT_ATTENTION", "PYTORCH_SDPA_CUDNN_ATTENTION"]
+    torch.manual_seed(3)
+    q, k, v = (torch.rand(1, 37, 128) for _ in range(3))
+    mask = torch.triu(torch.ones(37, 37), diagonal=1)
+    want = scaled_dot_product_attention(NAIVE, queries=q, keys=k, values=v, num_heads=2, causal_mask=mask)
+    got = scaled_dot_product_attention(ScaledDotProductAttentionBackend.PYTORCH_SDPA_MATH, queries=q, keys=k, values=v,
+                                       num_heads=2, causal_mask=None)
+    assert got.shape == want.shape and (got - want).abs().max().item() < 1e-6
+
+
 def test_extension_import_registers_op_with_reference_schema():
     load_attention_backend(CUSTOM)           # == `import causal_multihead_self_attention`
     op = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_torch

@@ -56,14 +56,14 @@ def test_greedy_step_equals_the_torch_chain(gpu_device):
         logits[1, eos] = 60.0                                         # this row generates EOS now
         logits[2, 0] = 70.0                                           # first element
         logits[3, vocab - 1] = 70.0                                   # last element (that is EOS as well)
-        logits[4, 123] = float("nan"); logits[4, 5] = 45.0            # NaN never wins
+        logits[4, 123] = float("nan"); logits[4, 5] = 45.0            # NaN ranks above every number (torch.argmax)
+        logits[4, 30000] = float("nan")                               # ... and the FIRST NaN wins
         done = torch.zeros(B, dtype=torch.bool, device=gpu_device)
         done[5] = True                                                # a finished row keeps receiving EOS
         tokens = torch.randint(0, vocab, (B, cap), device=gpu_device)
         pos = torch.tensor([10 + trial], device=gpu_device)
-        # the torch chain of BucketedGreedyGenerator._step (NaN replaced: torch.argmax would pick it)
-        clean = torch.nan_to_num(logits, nan=float("-inf"))
-        nxt = torch.argmax(clean, dim=-1)
+        # the torch chain of BucketedGreedyGenerator._step = reference sampler.py:17
+        nxt = torch.argmax(logits, dim=-1)
         nxt = torch.where(done, torch.full_like(nxt, eos), nxt)
         want_done = done | (nxt == eos)
         want_tokens = tokens.clone()
@@ -72,8 +72,8 @@ def test_greedy_step_equals_the_torch_chain(gpu_device):
         op(view, done, tokens, pos, eos)
         assert torch.equal(tokens, want_tokens) and torch.equal(done, want_done)
         assert int(pos) == 10 + trial                                 # pos is the caller's to increment
-        assert tokens[0, int(pos) + 1].item() == 777 and tokens[4, int(pos) + 1].item() == 5
-    # a row of NaNs picks index 0 (documented), a row of -inf as well (torch.argmax's answer)
+        assert tokens[0, int(pos) + 1].item() == 777 and tokens[4, int(pos) + 1].item() == 123
+    # a row of NaNs picks index 0, a row of -inf as well (torch.argmax's answers)
     weird = torch.full((2, vocab), float("nan"), device=gpu_device)
     weird[1] = float("-inf")
     d2 = torch.zeros(2, dtype=torch.bool, device=gpu_device)

@@ -148,6 +148,69 @@ def test_torch_op_uses_its_per_stream_workspace(gpu_device):
     assert (static_out - want).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize("T", [512, 768, 1024])
+def test_captured_op_runs_the_eager_plans(T, gpu_device):
+    """A graph captured on a stream that already has a workspace -- torch's recipe: warm up on the capture stream, or the
+    op reserve_workspace() -- runs the SAME plan as an eager call (T = 768 / 1024: query blocks split across workgroups;
+    T = 512: the 16-key-tile family, no scratch at all): bits equal to the eager workspace call, replayed twice with new
+    inputs in the static buffers."""
+    import causal_multihead_self_attention  # noqa: F401
+
+    ops = torch.ops.causal_multihead_self_attention
+    H = 12
+    ws = cmhsa.Workspace(gpu_device)
+    static_qkv = torch.empty(1, T, 3 * 64 * H, device=gpu_device)
+    q, k, v = (static_qkv[0, :, i * 64 * H:(i + 1) * 64 * H] for i in range(3))
+    for recipe in ("warm-up on the capture stream", "reserve_workspace"):
+        s = torch.cuda.Stream(device=gpu_device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            if recipe == "reserve_workspace":
+                need = ops.reserve_workspace(static_qkv, 1, T, H)
+                assert need == cmhsa.load_library().cmhsa_fp32_fwd_workspace_bytes(1, T, H)
+                assert (need > 0) == (T >= 768)
+            else:
+                static_qkv.normal_()
+                ops.causal_multihead_self_attention_torch(Q=q, K=k, V=v, num_heads=H)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            static_out = ops.causal_multihead_self_attention_torch(Q=q, K=k, V=v, num_heads=H)
+        for seed in (1, 2):
+            _, (nq, nk, nv) = _qkv(1, T, H, 100 * T + seed, gpu_device)
+            static_qkv[0, :, :64 * H], static_qkv[0, :, 64 * H:2 * 64 * H], static_qkv[0, :, 2 * 64 * H:] = nq[0], nk[0], nv[0]
+            g.replay()
+            torch.cuda.synchronize()
+            want = cmhsa.attention_fwd(q, k, v, H, workspace=ws)
+            assert torch.equal(static_out, want), (T, recipe, seed)
+        _check_against_oracle(static_out.unsqueeze(0), q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0), H, heads=(0, H - 1))
+
+
+def test_workspace_cache_is_sized_by_need_and_bounded(gpu_device):
+    """The op keeps one workspace per (device, stream), sized by the shape's need (none for shapes that split nothing) and
+    at most 16 of them: many short-lived streams must not pile up 8.7 MB each."""
+    import causal_multihead_self_attention  # noqa: F401
+
+    op = torch.ops.causal_multihead_self_attention.causal_multihead_self_attention_torch
+    _, (q, k, v) = _qkv(1, 1024, 12, 9, gpu_device)
+    want = op(Q=q[0], K=k[0], V=v[0], num_heads=12)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated(gpu_device)
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(40)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            got = op(Q=q[0], K=k[0], V=v[0], num_heads=12)
+        s.synchronize()
+        assert torch.equal(got, want)
+    del got
+    grown = torch.cuda.memory_allocated(gpu_device) - base
+    need = cmhsa.load_library().cmhsa_fp32_fwd_workspace_bytes(1, 1024, 12)
+    assert 0 < need < 2 ** 20
+    assert grown <= 16 * 2 ** 20 + 4 * 2 ** 20, grown          # <= 16 entries of 1 MiB (+ the output tensor just freed)
+
+
 @pytest.mark.parametrize("env", [{"CMHSA_PACKED": "7", "CMHSA_SPLIT": "1"}, {"CMHSA_PACKED": "8", "CMHSA_SPLIT": "1"},
                                  {"CMHSA_PACKED": "5", "CMHSA_SPLIT": "1"}, {"CMHSA_PACKED": "9", "CMHSA_SPLIT": "0"},
                                  {"CMHSA_PACKED": "12", "CMHSA_SPLIT": "1"},
