@@ -73,6 +73,9 @@ def parse_args():
                     help="device ramp before the warm-up steps: milliseconds of back-to-back launches of the workload (0 = none)")
     ap.add_argument("--gen-budget", type=float, default=120.0,
                     help="seconds the generation legs (GPT2 512-token runs, config 1 on the CPU, config 4 sample) may take in all")
+    ap.add_argument("--rendezvous-timeout", type=float, default=120.0,
+                    help="seconds torch.distributed may wait for the other ranks (rendezvous, and every collective under gloo; RCCL "
+                         "collectives are additionally watched by --extras-limit): a missing rank fails the run in seconds, not torch's 10-30 min")
     ap.add_argument("--extras-limit", type=float, default=420.0,
                     help="seconds the legs after the headline may take before the line is printed without them (a stalled collective "
                          "or a failed rank must not cost the headline measurement)")
@@ -88,6 +91,9 @@ def self_launch(args) -> int:
         port = s.getsockname()[1]
     procs = []
     for rank in range(args.gpus):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool support dmabuf IPC only; with the legacy mode RCCL's peer-memory
+        # set-up (and any device-tensor sharing between processes) fails with `hipIpcGetMemHandle: invalid argument`.  The
+        # harness exports it already; it is repeated here so that ranks started from a shell without it still come up.
         env = {**os.environ, "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(args.gpus),
                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
@@ -184,7 +190,10 @@ class Bench:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(self.backend, **({"device_id": self.dev} if self.backend == "nccl" else {}))
+            import datetime
+
+            dist.init_process_group(self.backend, timeout=datetime.timedelta(seconds=args.rendezvous_timeout),
+                                    **({"device_id": self.dev} if self.backend == "nccl" else {}))
             self.dist = dist
         import cmhsa
 
@@ -340,6 +349,7 @@ class Bench:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "ramp_launches": ramp["launches"],               # untimed launches of the device ramp that ran BEFORE the warm-up steps
             "ms_per_step": round(step_s * 1e3, 6),
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
@@ -360,6 +370,9 @@ class Bench:
                        "value_from_wall_clock": round(world * flops / (wall / args.steps) / 1e12, 3),
                        "priming_launches_after_fence": prime, "device_ramp": ramp},
             "percent_of_fp32_mfma_peak": round(100 * achieved / FP32_MFMA_PEAK_TFLOPS, 2),
+            "percent_of_fp32_mfma_peak_first_100_launches_from_idle": (
+                round(100 * flops / (ramp["us_per_launch_first_100_launches_from_idle"] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 2)
+                if ramp.get("us_per_launch_first_100_launches_from_idle") else None),
             "max_abs_err_vs_f64_oracle": max_err,
             "peak_assumes_clock_mhz": 2400,
             "sustained_shader_clock_mhz_under_fp32_mfma_load": round(clock_mhz, 0),
@@ -386,6 +399,25 @@ class Bench:
         others["config5_shard"] = {"workload": o["desc"], "us_per_launch": round(us, 2), "tflops": round(tf, 2),
                                    "frac_of_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "warmup": 20, "reps": 20}
         del q, k, v, oo
+        # BASELINE configs[4] WHOLE on this one GPU (B=32, H=16, T=4096: the N = 1 point of the head-sharded config; nothing to
+        # gather), with one (batch, head) checked against the f64 oracle outside the timed region
+        o = WORKLOADS["config5"]
+        q, k, v = self.sliced_inputs(o["B"], o["T"], o["H"])
+        oo = torch.empty((o["B"], o["T"], 64 * o["H"]), device=self.dev)
+        a = self.fwd_args(q, k, v, oo, o["B"], o["T"], o["H"])
+        us = self.events_us(lambda: self.launch(a), reps=10, warm=5)
+        tf = self.cmhsa.algorithmic_flops(o["B"], o["T"], o["H"], 64) / us / 1e6
+        from oracle import naive_attention as oracle
+        bb, hh = o["B"] - 1, o["H"] // 2
+        sl = slice(64 * hh, 64 * hh + 64)
+        want = oracle.naive_attention_f64(q[bb, :, sl].cpu().numpy(), k[bb, :, sl].cpu().numpy(), v[bb, :, sl].cpu().numpy(), 1)
+        others["config5_whole_on_one_gpu"] = {"workload": "synthetic causal attention fp32 B=32 H=16 T=4096 d_head=64, all 16 heads on one GPU",
+                                              "us_per_launch": round(us, 2), "tflops": round(tf, 2),
+                                              "frac_of_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "warmup": 5, "reps": 10,
+                                              "max_abs_err_vs_f64_oracle_one_batch_head": float(abs(oo[bb, :, sl].cpu().numpy() - want).max()),
+                                              "plan": self.cmhsa.plan_description(o["B"], o["T"], o["H"], self.workspace.nbytes)}
+        del q, k, v, oo, want
+        torch.cuda.empty_cache()
         # SURVEY 8(d) config 2 asks for more than the headline: contiguous as well as QKV-sliced inputs, randn as well
         # as rand, and the latency of ONE launch (launch -> completion seen by the host) next to the back-to-back rate
         c2 = WORKLOADS["config2"]
@@ -533,6 +565,27 @@ class Bench:
         torch.cuda.synchronize(self.dev)
         att_s = e0.elapsed_time(e1) * 1e-3
         small["attention_kernel_seconds_6048_launches"] = round(att_s, 4)
+        # the same 6 048 launches captured once into a HIP graph and replayed: device time without the host's launch cost
+        # (the eager figure above is host-bound wherever a launch is shorter than the ~3-4 us a ctypes call takes)
+        cap = torch.cuda.Stream(self.dev)
+        cap.wait_stream(self.stream)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cap):
+            cs = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            for a in launches:
+                for _ in range(12):
+                    self.launch(a[:18] + (cs,))
+        graph.replay()
+        torch.cuda.synchronize(self.dev)
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record(self.stream)
+        graph.replay()
+        g1.record(self.stream)
+        torch.cuda.synchronize(self.dev)
+        small["attention_kernel_seconds_6048_launches_one_hip_graph"] = round(g0.elapsed_time(g1) * 1e-3, 4)
+        small["attention_tflops_over_the_6048_launches_hip_graph"] = round(
+            sum(12 * self.cmhsa.algorithmic_flops(1, T, H, 64) for T in range(8, 512)) / (g0.elapsed_time(g1) * 1e-3) / 1e12, 2)
+        del graph
         small["attention_share_of_reference_loop_hip"] = round(att_s / small["reference_loop_hip_kernel"]["seconds"], 4)
         small["attention_share_of_hip_graph_loop"] = round(att_s / small["hip_graphs_fused_gelu_hip_kernel"]["seconds"], 4)
         # opt-in KV-cache mode (NOT the reference's algorithm, which keeps no cache): one position per token
@@ -647,15 +700,22 @@ class Bench:
 
     def config4_dp_leg(self, budget_s: float) -> dict | str:
         """BASELINE configs[3]: GPT2-XL, 64 copies of the reference prompt split evenly over the ranks (data-parallel,
-        replicated weights, no collective on the data path), HIP-graph loop + fused GELU.  A bounded sample: the total
-        length is 72 tokens (64 generated per prompt) unless the budget allows the full 512."""
+        replicated weights, no collective on the data path), every prompt to 512 total tokens.  Two forms, each labelled:
+          kv_cache_512_tokens   the config at its stated length through the opt-in KV-cache loop (one HIP graph per token
+                                step; NOT the reference's algorithm, which keeps no cache; ~4 s on one GPU);
+          graph_loop            the reference's algorithm (full re-forward per token) as HIP graphs + fused kernels: at its
+                                stated 512 tokens it takes ~210 s per run on one GPU (profiles/generation/
+                                config4_xl_b64_t512_graphs_fusedgelu.json), so it runs at full length only when
+                                --gen-budget allows (>= 500 s left) and otherwise as a 72-token sample, labelled as such."""
         torch = self.torch
         import gpt2_generation as gen
         from causal_self_attention import ScaledDotProductAttentionBackend as Backend
 
         if budget_s < 25:
             return "skipped: generation time budget (--gen-budget) spent"
-        n_prompts, max_tokens = 64, 72
+        t_start = time.perf_counter()
+        left = lambda: budget_s - (time.perf_counter() - t_start)
+        n_prompts = 64
         model_name = "gpt2-xl"
         overrides = None
         if self.backend != "nccl":
@@ -664,26 +724,42 @@ class Bench:
         prompts = [list(gen.REFERENCE_PROMPT_IDS) for _ in mine]
         model = gen.build_model(model_name, Backend.CUSTOM_CUDA, self.dev, seed=0, fused_gelu=True, fused_add_ln=True, fused_step_ops=True,
                                 init_on_device=True, overrides=overrides)
+
+        def timed(g, max_tokens, label):
+            g.generate(prompts)                                  # captures the graphs (warm-up)
+            self.fence()
+            t0 = time.perf_counter()
+            toks = g.generate(prompts)
+            torch.cuda.synchronize(self.dev)
+            seconds = time.perf_counter() - t0
+            generated = float(sum(len(t) - len(gen.REFERENCE_PROMPT_IDS) for t in toks))
+            (seconds,) = self.max_over_ranks(seconds)
+            if self.dist is not None:
+                t = torch.tensor([generated], device=self.dev, dtype=torch.float64)
+                self.dist.all_reduce(t)
+                generated = float(t[0])
+            return toks, {"loop": label, "max_tokens": max_tokens, "full_length_of_the_config": max_tokens == 512,
+                          "seconds": round(seconds, 3), "tokens_generated_all_gpus": int(generated),
+                          "tokens_per_second_all_gpus": round(generated / seconds, 1),
+                          "rows_identical_on_rank0": bool(all(row == toks[0] for row in toks))}
+
+        res = {"workload": f"{model_name} fp32, {n_prompts} prompts over {self.world} GPU(s) ({len(prompts)} on rank 0), 512 total tokens each"}
+        kv = gen.KVCacheGreedyGenerator(model, len(prompts), 512, device=self.dev)
+        toks_kv, res["kv_cache_512_tokens"] = timed(kv, 512, "opt-in KV cache, one HIP graph per token step, fused GELU / add + LayerNorm / step kernels")
+        del kv
+        torch.cuda.empty_cache()
+        # every rank must take the same branch: decide on the slowest rank's clock
+        (room,) = self.max_over_ranks(-left())
+        full = -room >= 500.0
+        max_tokens = 512 if full else 72
         g = gen.BucketedGreedyGenerator(model, len(prompts), max_tokens, bucket=64, device=self.dev)
-        g.generate(prompts)                                      # captures the graphs (warm-up)
-        self.fence()
-        t0 = time.perf_counter()
-        toks = g.generate(prompts)
-        torch.cuda.synchronize(self.dev)
-        seconds = time.perf_counter() - t0
-        generated = float(sum(len(t) - len(gen.REFERENCE_PROMPT_IDS) for t in toks))
-        (seconds,) = self.max_over_ranks(seconds)
-        if self.dist is not None:
-            t = torch.tensor([generated], device=self.dev, dtype=torch.float64)
-            self.dist.all_reduce(t)
-            generated = float(t[0])
-        rows_equal = all(row == toks[0] for row in toks)
+        toks_g, res["graph_loop"] = timed(g, max_tokens, "reference algorithm (no KV cache) as HIP graphs per 64-token bucket + fused kernels"
+                                          + ("" if full else "; BOUNDED SAMPLE: 72 of the config's 512 tokens"))
+        res["graph_loop"]["tokens_identical_to_kv_cache_loop_on_the_common_prefix"] = bool(
+            all(a[:max_tokens] == b2[:max_tokens] for a, b2 in zip(toks_g, toks_kv)))
         del g, model
         torch.cuda.empty_cache()
-        return {"workload": f"{model_name} fp32, {n_prompts} prompts over {self.world} GPU(s) ({len(prompts)} on rank 0), "
-                            f"{max_tokens} total tokens each (bounded sample of the 512-token config), HIP graphs + fused GELU, add + LayerNorm and step kernels",
-                "seconds": round(seconds, 3), "tokens_generated_all_gpus": int(generated),
-                "tokens_per_second_all_gpus": round(generated / seconds, 1), "rows_identical_on_rank0": bool(rows_equal)}
+        return res
 
 
 def main() -> None:
@@ -696,8 +772,9 @@ def main() -> None:
         faulthandler.dump_traceback_later(int(os.environ["CMHSA_BENCH_WATCHDOG"]), exit=True)
     b = Bench(args)
     result = b.headline()
-    if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], b.torch)
+    if b.rank == 0 and not args.no_cpu_baseline:
+        # (N > 1: a shorter sample -- the other ranks wait for rank 0 at the next barrier)
+        result["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], b.torch, budget_s=20.0 if b.world == 1 else 6.0)
     if not args.no_extras:
         # The legs below run collectives and minutes of generation that the headline does not depend on.  If they are
         # not done after --extras-limit seconds (a rank died inside a leg, a collective stalled) every rank leaves on

@@ -700,6 +700,22 @@ hipError_t launch(const Params &p, dim3 grid, void *stream) {
                            lds_bytes(kWaves, kSegs), static_cast<hipStream_t>(stream));
 }
 
+// 1 = the occupancy query says one workgroup of the 8-wave table variant (4 or 8 segments) per CU on this device; cached.
+bool one_workgroup_per_cu(int dev, bool eight_segments) {
+    static std::atomic<int> cached[2][64];                // 0 = not asked yet, 1 = yes, 2 = no
+    std::atomic<int> *slot = (dev >= 0 && dev < 64) ? &cached[eight_segments ? 1 : 0][dev] : nullptr;
+    int v = slot ? slot->load(std::memory_order_relaxed) : 0;
+    if (!v) {
+        int blocks = 0;
+        const hipError_t e = eight_segments
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cmhsa_fwd_kernel<8, 8, false>, 512, lds_bytes(8, 8))
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, cmhsa_fwd_kernel<8, 4, false>, 512, lds_bytes(8, 4));
+        v = (e == hipSuccess && blocks == 1) ? 1 : 2;
+        if (slot) slot->store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+
 // ---- the no-allocation entry point's scratch: a file-scope array in device memory.  In HOST code the name `scratch`
 // is only a stand-in (not a device address): its address on each device comes from hipGetSymbolAddress, once per
 // device, and only that pointer is ever handed to a kernel.  Zero-initialised at module load, like every arrival
@@ -883,6 +899,11 @@ int forward(const float *q, const float *k, const float *v, float *o,
     p.splits_per_bh = plan.splits_per_bh;
     if (plan.use_table) memcpy(p.seg_table, plan.table, sizeof(unsigned) * (size_t)plan.n_wgs * 2 * plan.segs);
 
+    // The hand-off of a split block without an acquire (sc1 stores, drained, one counter add, sc1 loads: MI355X guide,
+    // visibility table row 1) is measured for ONE workgroup per CU.  That holds by the LDS footprint of the 8-wave table
+    // variants (98 / 130 KiB of 160); it is ASKED of the runtime once per device and variant, and if the answer is not 1
+    // (another device, another LDS size) the merging workgroup runs the agent-scope acquire after all.
+    if (split && !acquire) acquire = !one_workgroup_per_cu(dev, plan.segs == 8);
     hipError_t e;
     if (waves == 1) e = launch<1, 2, false>(p, grid, stream);
     else if (!p.use_table) e = waves == 8 ? launch<8, 2, false>(p, grid, stream) : launch<4, 2, false>(p, grid, stream);
@@ -963,10 +984,14 @@ int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspac
                  (long long)bh, cus, pl.t16.blocks, pl.t16.tiles_per_simd, pl.t16.max_jobs, pl.t16.contig ? "XCD-contiguous" : "2-D", pl.cycles);
         return CMHSA_OK;
     }
-    snprintf(buf, (size_t)buf_len, "%s: %d-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, chain cap %d, SIMD cap %d, "
-             "%d of %lld query blocks per (b,h) split across workgroups, workspace %zu B, estimate %.0f cycles",
-             pl.family, pl.pp.waves, pl.pp.wgs_per_bh, (long long)bh, cus, pl.pp.chain, pl.simd_cap, pl.splits_per_bh,
-             (long long)nqb, plan_workspace_bytes(pl, bh), pl.cycles);
+    int n = snprintf(buf, (size_t)buf_len, "%s: %d-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, chain cap %d, SIMD cap %d, "
+                     "%d of %lld query blocks per (b,h) split across workgroups, workspace %zu B, estimate %.0f cycles",
+                     pl.family, pl.pp.waves, pl.pp.wgs_per_bh, (long long)bh, cus, pl.pp.chain, pl.simd_cap, pl.splits_per_bh,
+                     (long long)nqb, plan_workspace_bytes(pl, bh), pl.cycles);
+    if (pl.parts_per_bh > 0 && n > 0 && n < buf_len && dev >= 0)
+        snprintf(buf + n, (size_t)(buf_len - n), one_workgroup_per_cu(dev, pl.segs == 8)
+                 ? "; hand-off without acquire (occupancy query: one workgroup per CU)"
+                 : "; hand-off with agent-scope acquire (occupancy query: not one workgroup per CU)");
     return CMHSA_OK;
 }
 

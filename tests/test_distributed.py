@@ -153,7 +153,11 @@ def test_bench_self_launches_two_ranks_in_rehearsal_mode():
     c5 = line["config5"]
     assert c5["gathered_max_abs_err_vs_f64_oracle"] <= 1e-4 and c5["end_to_end_ms_incl_permute"] > 0
     c4 = line["config4_dp"]
-    assert c4["tokens_generated_all_gpus"] > 0 and c4["rows_identical_on_rank0"]
+    for form in ("kv_cache_512_tokens", "graph_loop"):
+        assert c4[form]["tokens_generated_all_gpus"] > 0 and c4[form]["rows_identical_on_rank0"]
+    assert c4["kv_cache_512_tokens"]["full_length_of_the_config"] and not c4["graph_loop"]["full_length_of_the_config"]
+    assert c4["graph_loop"]["tokens_identical_to_kv_cache_loop_on_the_common_prefix"]
+    assert line["cpu_baseline"]["cores"] >= 1 and line["ramp_launches"] > 0        # N > 1 lines carry the CPU baseline too
 
 
 @pytest.mark.gpu

@@ -45,6 +45,9 @@ def test_config2_uses_a_split_plan_and_matches_the_oracle(gpu_device):
     assert ws.nbytes == cmhsa.load_library().cmhsa_workspace_bytes()
     desc = cmhsa.plan_description(1, 1024, 12, ws.nbytes)
     assert "split across workgroups" in desc and " 0 of 32" not in desc, desc       # the plan under test really splits
+    # the acquire-free hand-off is measured for one workgroup per CU: the launcher asks the occupancy query (and falls back to
+    # the acquire variant otherwise); on this device the 98 KiB LDS footprint gives exactly one
+    assert "hand-off without acquire (occupancy query: one workgroup per CU)" in desc, desc
     assert cmhsa.load_library().cmhsa_fp32_fwd_workspace_bytes(1, 1024, 12) > 0
     _, (q, k, v) = _qkv(1, 1024, 12, 1, gpu_device)
     out = torch.full((1, 1024, 768), float("nan"), device=gpu_device)
