@@ -279,31 +279,44 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fwd16_kernel(Params16 p) {
             STAMP(stamp_i);
 #endif
             // ---- S^T[key][query] = sum_d K[key][d] Q[query][d], tile A then tile B; at least two independent chains in
-            //      turn (the shape's dependent latency is 40 cycles against 32 of issue).  Behind a tile's chain: K of
-            //      the next step into its registers (the softmax and the PV chain to land). ----
+            //      turn (the shape's dependent latency is 40 cycles against 32 of issue).  K of the NEXT step goes into the
+            //      registers as they fall free, one load behind each group of MFMAs (issued under the matrix pipe's
+            //      shadow, not in a burst in front of the softmax): tile A's between the groups of tile B's chain, tile
+            //      B's between the first PV k-steps. ----
             f32x4 sc[kSub][2];
+            {
+                f32x4 ch[2][kSub][kPar];
 #pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
-                f32x4 ch[kSub][kPar];
+                for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-                for (int s = 0; s < kSub; ++s)
+                    for (int s = 0; s < kSub; ++s)
 #pragma unroll
-                    for (int q2 = 0; q2 < kPar; ++q2) ch[s][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (tl == 0 || has_b) {
+                        for (int q2 = 0; q2 < kPar; ++q2) ch[tl][s][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int s = 0; s < kSub; ++s)
+                            ch[0][s][jj % kPar] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[0][c][jj], qf[s][4 * c + jj], ch[0][s][jj % kPar], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has_b) {
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                             for (int s = 0; s < kSub; ++s)
-                                ch[s][jj % kPar] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[tl][c][jj], qf[s][4 * c + jj], ch[s][jj % kPar], 0, 0, 0);
+                                ch[1][s][jj % kPar] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[1][c][jj], qf[s][4 * c + jj], ch[1][s][jj % kPar], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    kb[0][c] = load16(ksn, koffs[0][c]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) kb[tl][c] = load16(ksn, koffs[tl][c]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-                for (int s = 0; s < kSub; ++s) sc[s][tl] = kPar == 2 ? ch[s][0] + ch[s][kPar - 1] : ch[s][0];
+                    for (int s = 0; s < kSub; ++s) sc[s][tl] = kPar == 2 ? ch[tl][s][0] + ch[tl][s][kPar - 1] : ch[tl][s][0];
             }
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 1);
@@ -385,6 +398,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fwd16_kernel(Params16 p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     vb[tl][i] = load16(vsn, voffs[tl][i]);
+                    if (tl == 0) kb[1][i] = load16(ksn, koffs[1][i]);
                 }
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 3);

@@ -43,7 +43,7 @@ for (B, H, T, dist) in [(1, 12, 1, "randn"), (1, 12, 7, "randn"), (1, 12, 16, "r
             sl = slice(64 * h, 64 * h + 64)
             want = oracle.naive_attention_f64(buf[b, :, sl], buf[b, :, d + 64 * h:d + 64 * h + 64], buf[b, :, 2 * d + 64 * h:2 * d + 64 * h + 64], 1)
             err = max(err, float(np.abs(o[b, :, sl] - want).max()))
-    is16 = desc.startswith("16-row")
+    is16 = desc.startswith("16-key tiles")
     n16_seen += is16
     print(f"B={B} H={H} T={T} {dist}: max err {err:.2e}  [{desc.split(':')[0]}]", flush=True)
     worst = max(worst, err)
