@@ -174,6 +174,19 @@ def plan_dump(batch: int, seq_len: int, num_heads: int, with_workspace: bool = F
         plan["merges"] = [[bool(wave[0] >> 31) for wave in wg] for wg in words]
         plan["raw_words"] = words
         return plan
+    if plan["use_table"] == 3:
+        # job lists (one-wave workgroups, the kernel's kList variant): "chain" = (b,h)s per period, "n_paired" = lists per
+        # period (= grid_y), "simd_cap" = units of the longest list; per list its jobs as (units of the block = block index
+        # + 1, (b,h) within the period); "descending_up_to" = blocks of at most that many units are taken from the diagonal
+        # unit down.  Period P = 8 * z + x of the grid covers the (b,h)s [P * period_bh, (P + 1) *
+        # period_bh) that exist; a list's entries whose (b,h) does not exist are dropped by the kernel.
+        plan.update(family="lists", period_bh=plan["chain"], lists_per_period=plan["n_paired"], units_per_list=plan["simd_cap"],
+                    jobs_per_list=plan["n_alone"], descending_up_to=plan["workspace_256"], workspace_256=0)
+        words = [[buf[16 + l * 8 + i] & 0xffffffff for i in range(8)] for l in range(plan["lists_per_period"])]
+        entries = [[(w >> (16 * h)) & 0xffff for w in ws for h in (0, 1)] for ws in words]
+        plan["lists"] = [[(e & 255, e >> 8) for e in es if e & 255] for es in entries]
+        plan["raw_words"] = words
+        return plan
     plan["family"] = "units32"
     segs = plan["segs"]
     plan["workgroups"] = [[tuple(buf[16 + (j * segs + i) * 5: 16 + (j * segs + i) * 5 + 5]) for i in range(segs)

@@ -59,6 +59,10 @@ struct Params {
     float *ws_parts;
     unsigned *ws_counters;
     int parts_per_bh, splits_per_bh;
+    // job lists (one-wave workgroups, the kernel's kList): list_p consecutive (b,h)s form a period whose blocks are dealt
+    // to the gridDim.y lists of seg_table (8 words = 16 half-word entries each: units | (b,h) within the period << 8; 0 = end)
+    int list_p, list_periods;
+    int list_rev_max;                   // blocks of at most this many units are taken from the diagonal unit DOWN (0 = none)
     unsigned seg_table[kTableSize];
 };
 

@@ -143,8 +143,19 @@ __device__ __forceinline__ void store_o(float *ptr, f32x4 v, bool in_range) {
 // kWaves = 1: a workgroup is ONE wave that runs its (up to two) query blocks one after the other, whole -- no split-KV,
 // no shared LDS, no barrier, O straight from the accumulators.  For grids of many rounds: every wave slot of the chip is
 // refilled on its own, and with the pairing n <-> nqb+1-n every wave runs the same nqb+1 units.
-template <int kWaves, int kSegs, bool kAcquire>
+// kList (one-wave workgroups only): the wave runs a LIST of up to 16 whole query blocks of SEVERAL (b,h)s, one after the
+// other, with the K / V prefetch stream and the query prefetch running on across every boundary.  The lists come from the
+// host (Params::seg_table: 8 words = 16 half-word entries per list, `units | (b,h) within the period << 8`, 0 = end).  Blocks
+// of at most list_rev_max units are taken in DESCENDING order, from the diagonal unit down to unit 0: the waves of a team
+// whose (short) blocks END together then read the same K / V unit at the same time, as the waves whose (long) blocks START
+// together do in ascending order.  The order is a function of the block's length alone, so a block's result does not depend
+// on the list it is on (equal prompts in a batch give bit-equal rows).  A
+// PERIOD of list_p consecutive (b,h)s is dealt to list_q waves so that every wave carries (almost) the same number of
+// units and the whole launch is ONE round of equally long waves -- no round quantisation, one prologue per wave
+// instead of one per 17-unit job.  Grid = (8, list_q, periods / 8): x is the XCD, so a period's waves share an L2.
+template <int kWaves, int kSegs, bool kAcquire, bool kList = false>
 __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
+    static_assert(!kList || (kWaves == 1 && kSegs == 2 && !kAcquire), "job lists: one-wave workgroups");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int lane = threadIdx.x & 63;
@@ -174,6 +185,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                      "s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs), "s"(p.v_rs), "s"(p.o_rs));
     } else
     asm volatile("" ::"s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs), "s"(p.v_rs), "s"(p.o_rs));
+    unsigned lw[8];                             // kList: this wave's list, as it stands in the table
+    if constexpr (kList) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lw[i] = p.seg_table[blockIdx.y * 8 + i];
+        asm volatile("" ::"s"(lw[0]), "s"(lw[1]), "s"(lw[2]), "s"(lw[3]), "s"(lw[4]), "s"(lw[5]), "s"(lw[6]), "s"(lw[7]), "s"(p.list_p), "s"(p.list_periods), "s"(p.list_rev_max));
+    }
     asm volatile("" ::"s"(p.q_bs), "s"(p.k_bs), "s"(p.v_bs), "s"(p.o_bs), "s"(p.seq_len), "s"(p.num_heads), "s"(p.nqb),
                  "s"(p.grid_x), "s"(p.heads_magic), "s"(p.chain_magic), "s"(p.chain), "s"(p.n_paired), "s"(p.n_alone), "s"(p.use_table));
     STAMP(124);
@@ -181,15 +198,41 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     // ---- grid -> (batch*head, workgroup j of that head).  Workgroups are dispatched in linear order, x fastest,
     //      round-robin over the 8 XCDs: with grid = (8, wgs_per_bh, bh/8) every XCD keeps its own (b,h)s (K/V
     //      stay in that XCD's L2), with grid = (bh, wgs_per_bh, 1) otherwise; either way j = 0 (heaviest) first.
-    const int bh = blockIdx.z * p.grid_x + blockIdx.x;
+    int bh = blockIdx.z * p.grid_x + blockIdx.x;
     const int j = blockIdx.y;
-    if constexpr (kWaves == 1) {
+    if constexpr (kWaves == 1 && !kList) {
         if (bh >= p.bh_count) return;            // padding of the longest-first grid (no barrier in this variant)
+    }
+    // kList: the list's entries whose (b,h) exists (the last period may be short), packed into the lanes of one register:
+    // job i = lane i, wave-uniform and dynamic; lanes past the last job hold 0 = "no job"
+    unsigned jobs_v = 0;
+    int period_bh0 = 0;
+    if constexpr (kList) {
+        const int period = blockIdx.z * 8 + blockIdx.x;
+        if (period >= p.list_periods) return;   // padding of the grid's z (no barrier in this variant)
+        period_bh0 = period * p.list_p;
+        const unsigned limit = (unsigned)(p.bh_count - period_bh0);
+        int njobs = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned e = (lw[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            if ((e & 255u) != 0u && (e >> 8) < limit) {
+                jobs_v = lane == njobs ? e : jobs_v;
+                ++njobs;
+            }
+        }
+        if (njobs == 0) return;                  // (a list whose every (b,h) is past the end)
+        bh = period_bh0 + (int)((unsigned)__builtin_amdgcn_readlane((int)jobs_v, 0) >> 8);
     }
     // ---- workgroup j -> up to kSegs query blocks ("segments"), this wave -> (segment, local wave index) ----
     int seg_n[kSegs];                           // units (= query block index + 1) of each segment's query block; 0 = none
     int seg_ulo[kSegs], seg_cnt[kSegs];          // the segment covers units [ulo, ulo + cnt) of it (the whole block: 0, n)
     unsigned seg_mask[kSegs], seg_x[kSegs];      // waves working on it (bit w = wave w); table word 1 (0 = not a part)
+    if constexpr (kList) {
+#pragma unroll
+        for (int i = 0; i < kSegs; ++i) { seg_n[i] = 0; seg_ulo[i] = 0; seg_cnt[i] = 0; seg_mask[i] = 0; seg_x[i] = 0; }
+        seg_n[0] = (int)((unsigned)__builtin_amdgcn_readlane((int)jobs_v, 0) & 255u);
+    } else
     decode_segments<kSegs>(tw, j, p.nqb, p.n_paired, p.n_alone, p.chain, p.chain_magic, seg_n, seg_ulo, seg_cnt, seg_mask, seg_x);
     // this wave -> (segment, index among the segment's waves); defaults = idle wave: barriers and row work only
     int u_first = 0, u_end = 0, qb = -1, seg_waves = 1, seg = 0, n_seg = 0;
@@ -213,6 +256,28 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
     const float *qg = p.q + (uint64_t)(uint32_t)b * (uint64_t)p.q_bs + (uint32_t)h * kHeadDim;
     const float *kg = p.k + (uint64_t)(uint32_t)b * (uint64_t)p.k_bs + (uint32_t)h * kHeadDim;
     const float *vg = p.v + (uint64_t)(uint32_t)b * (uint64_t)p.v_bs + (uint32_t)h * kHeadDim;
+    // kList: the two jobs after the current one (units; 0 = none) -- the prefetch stream looks two units ahead, and a job
+    // may be one unit long -- and where each finds its (b,h)
+    struct JobRef { int n; bool rev; const float *q, *k, *v; float *o; };
+    auto job_ref = [&](int i) {
+        const unsigned e = (unsigned)__builtin_amdgcn_readlane((int)jobs_v, i);
+        const int jbh = period_bh0 + (int)(e >> 8);
+        const int jb = udiv_magic(jbh, p.num_heads, p.heads_magic), jh = jbh - jb * p.num_heads;
+        JobRef r;
+        r.n = (int)(e & 255u);
+        r.rev = r.n <= p.list_rev_max;
+        r.q = p.q + (uint64_t)(uint32_t)jb * (uint64_t)p.q_bs + (uint32_t)jh * kHeadDim;
+        r.k = p.k + (uint64_t)(uint32_t)jb * (uint64_t)p.k_bs + (uint32_t)jh * kHeadDim;
+        r.v = p.v + (uint64_t)(uint32_t)jb * (uint64_t)p.v_bs + (uint32_t)jh * kHeadDim;
+        r.o = p.o + (uint64_t)(uint32_t)jb * (uint64_t)p.o_bs + (uint32_t)jh * kHeadDim;
+        return r;
+    };
+    JobRef job1 = {0, false, qg, kg, vg, nullptr}, job2 = job1;
+    bool cur_rev = false;                        // the current job takes its units in descending order
+    if constexpr (kList) {
+        job1 = job_ref(1); job2 = job_ref(2);
+        cur_rev = seg_n[0] <= p.list_rev_max;
+    }
 
     float *wlds = lds + wave * kUnitFloats;      // private to this wave: its current K unit (8 KiB); later its merge image
     float *qlds_all = lds + lds_floats_q(kWaves);                      // shared: the segments' query blocks,
@@ -297,7 +362,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         if constexpr (kDirectQ) {
             // this pass's first K unit and the query block's fragments straight from global memory in operand layout
             // (lane = query: eight 16-B pieces of its row), one round trip for both
-            load_unit(unit_rsrc(kg, p.k_rs, u_first * kKeyUnit, N), koff, kstep, kst);
+            load_unit(unit_rsrc(kg, p.k_rs, (kList && cur_rev ? u_end - 1 : u_first) * kKeyUnit, N), koff, kstep, kst);
             const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, qb * kQBlock, N);
             f32x4 qt[8];
 #pragma unroll
@@ -323,10 +388,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 
         // descriptor of the unit this wave processes d steps after unit u (zero records when there is none).  One-wave
         // workgroups: past the end of the block it is a unit of the wave's NEXT block.
-        auto ahead = [&](const float *base, int64_t rs, int u, int d) {
+        //  With job lists the next block is another (b,h)'s as a rule, and the one after it is reached when the next is a single unit.
+        auto ahead = [&](const float *base, int64_t rs, int u, int d, bool is_v = false) {
             int t = u + d * seg_waves;
             bool en = t < u_end;
-            if constexpr (kWaves == 1) {
+            if constexpr (kList) {               // (u counts the job's units in the order it takes them)
+                int n = u_end;
+                bool rev = cur_rev;
+                if (!en) {
+                    t -= u_end; base = is_v ? job1.v : job1.k; en = t < job1.n; n = job1.n; rev = job1.rev;
+                    if (!en) { t -= job1.n; base = is_v ? job2.v : job2.k; en = t < job2.n; n = job2.n; rev = job2.rev; }
+                }
+                if (rev) t = max(n - 1 - t, 0);
+            } else if constexpr (kWaves == 1) {
                 if (!en) { t -= u_end; en = t < n_after; }
             }
             return unit_rsrc(base, rs, t * kKeyUnit, N, en);
@@ -335,17 +409,23 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         // One unit = QK chain, softmax, PV chain.  `first` (compile time): the wave's first unit, whose QK chain
         // also carries the loads the steady state issues one unit ahead -- V(u) and K(u + seg_waves) -- so that
         // the first MFMA does not queue behind 24 more buffer loads per wave (a CU's L1 serves 64 B/clk).
-        auto unit = [&](const int u, auto first) __attribute__((always_inline)) {
-            constexpr bool kFirst = decltype(first)::value;
+        //  `last` (compile time, one-wave workgroups): the last unit of a block that another block follows: the query
+        //  fragments of that next block are requested right behind the QK chain -- the registers of this block's fragments
+        //  are free from there on -- and land under the softmax and the PV chain (requested after the chain, at the block
+        //  boundary, they cost the wave a whole memory round trip per block: 6-8 k cycles, measured).
+        f32x4 qt[8];                 // raw query fragments of the wave's next block
+        auto unit = [&](const int u, auto first, auto last) __attribute__((always_inline)) {
+            constexpr bool kFirst = decltype(first)::value, kLast = decltype(last)::value;
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i);
 #endif
             // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] : 32 chained MFMAs.  K fragments are read
             //      two steps (512 MFMA cycles) ahead. ----
             f32x16 s = {0};
+            const int ua = kList && cur_rev ? u_end - 1 - u : u;       // the unit's index in its block
             __amdgpu_buffer_rsrc_t vsrc0, ksrc1;
             if constexpr (kFirst) {
-                vsrc0 = unit_rsrc(vg, p.v_rs, u * kKeyUnit, N);
+                vsrc0 = unit_rsrc(vg, p.v_rs, ua * kKeyUnit, N);
                 ksrc1 = ahead(kg, p.k_rs, u, 1);
             }
 #pragma unroll
@@ -367,8 +447,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 #ifdef CMHSA_STAMPS
             STAMP(stamp_i + 1);
 #endif
+            if constexpr (kLast) {
+                const int n_next = kList ? job1.n : n_after;
+                const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(kList ? job1.q : qg, p.q_rs, max(n_next - 1, 0) * kQBlock, N, n_next != 0);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    qt[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (l31 * (int)p.q_rs + 8 * c + 4 * half) * 4, 0, 0));
+            }
             // ---- causal mask: only the diagonal unit has key > query pairs (CMHSA.cu:228, :249) ----
-            if (u == qb) {
+            if (ua == qb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (acc_row(r) + 4 * half > l31) s[r] = -INFINITY;
@@ -387,7 +474,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             __builtin_amdgcn_sched_barrier(0);           // (s_setprio is no scheduling barrier of its own)
             f32x16 pv;
             f32x2 psum2 = {0.f, 0.f};                 // packed fp32 ops: two elements per VALU issue slot
-            if constexpr (!kFirst) {                  // (the first unit goes straight to the max path below)
+            const bool fresh = kFirst || (kWaves == 1 && u == 0);     // a block's first unit goes straight to the max path below
+            if (!fresh) {
                 const f32x2 m2 = {m_run, m_run};
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
@@ -401,7 +489,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 }
             }
             float psum = psum2[0] + psum2[1];
-            if (kFirst || !__all(psum < kRescaleSum)) {          // NaN and inf compare false: they take this path too
+            if (fresh || !__all(psum < kRescaleSum)) {           // NaN and inf compare false: they take this path too
                 float mx = s[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -440,7 +528,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
             //      Everything is unconditional (past the last unit the descriptors have zero records and the
             //      LDS unit receives zeros nobody reads), so the chain stays one basic block.
             const __amdgpu_buffer_rsrc_t ksrc2 = ahead(kg, p.k_rs, u, 2);
-            const __amdgpu_buffer_rsrc_t vsrc1 = ahead(vg, p.v_rs, u, 1);
+            const __amdgpu_buffer_rsrc_t vsrc1 = ahead(vg, p.v_rs, u, 1, true);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (r < 8) {
@@ -470,22 +558,29 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
         };
 
         __builtin_amdgcn_s_setprio(2);
-        unit(u_first, std::true_type{});         // every active wave owns at least one unit (a segment has no more waves than units)
+        unit(u_first, std::true_type{}, std::false_type{});      // every active wave owns at least one unit (a segment has no more waves than units)
         if constexpr (kWaves > 1) {
-            for (int u = u_first + seg_waves; u < u_end; u += seg_waves) unit(u, std::false_type{});
+            for (int u = u_first + seg_waves; u < u_end; u += seg_waves) unit(u, std::false_type{}, std::false_type{});
             l_run = xhalf_sum(l_run);
         } else {
             float *__restrict__ og = p.o + (uint64_t)(uint32_t)b * (uint64_t)p.o_bs + (uint32_t)h * kHeadDim;
             int u = 1;
+            int ji = 0;                          // kList: index of the current job in the list
             for (;;) {
-                for (; u < u_end; ++u) unit(u, std::false_type{});
+                for (; u + 1 < u_end; ++u) unit(u, std::false_type{}, std::false_type{});
+                // the block's last unit, with the next block's query fragments requested inside it -- unless the block was
+                // the kernel's first and a single unit (its only unit ran above): then they are requested here
+                const bool prefetched = u < u_end;
+                if (prefetched) unit(u, std::false_type{}, std::true_type{});
+#ifdef CMHSA_STAMPS
+                STAMP(stamp_i);          // a block boundary shows as a row of its own: (chain issued, O stores issued, fragments scaled, 0)
+#endif
                 // the whole block was this wave's: normalise and store, lane = query, 4 consecutive d per store (the
                 // merge's pairs).  The next block's first K unit is in LDS and its first V unit in flight already; its
                 // query fragments are requested BEFORE the stores (the registers of this block's are free now)
-                const int n_next = n_after;
-                f32x4 qt[8];
-                if (n_next) {
-                    const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(qg, p.q_rs, (n_next - 1) * kQBlock, N);
+                const int n_next = kList ? job1.n : n_after;
+                if (n_next && !prefetched) {
+                    const __amdgpu_buffer_rsrc_t qsrc = unit_rsrc(kList ? job1.q : qg, p.q_rs, (n_next - 1) * kQBlock, N);
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
                         qt[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc, (l31 * (int)p.q_rs + 8 * c + 4 * half) * 4, 0, 0));
@@ -498,6 +593,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                     const int col = 2 * (2 * (pi & 1) + 8 * (pi >> 1) + 4 * half);
                     store_o(og + (int64_t)row * p.o_rs + col, t * inv, row < N);
                 }
+#ifdef CMHSA_STAMPS
+                STAMP(stamp_i + 1);
+#endif
                 if (!n_next) break;
                 // fresh accumulators; m_run = -inf sends the block's first unit down the max path (its row sums are not finite)
 #pragma unroll
@@ -505,10 +603,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 m_run = -INFINITY;
                 l_run = 0.f;
                 u_end = n_next; qb = n_next - 1; n_after = 0; u = 0;
+                if constexpr (kList) {           // the list moves up by one: the bases every later load and store goes through
+                    kg = job1.k; vg = job1.v; og = job1.o; cur_rev = job1.rev;
+                    job1 = job2;
+                    job2 = job_ref(ji + 3);
+                    ++ji;
+                }
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) qf[4 * c + j] = qt[c][j] * kScaleLog2;
+#ifdef CMHSA_STAMPS
+                STAMP(stamp_i + 2);
+                if (stamp_on && stamp_i + 3 < 128) stamp_ptr[stamp_i + 3] = 0;
+                stamp_i += 4;
+#endif
             }
         }
     }
@@ -679,16 +788,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
 #endif
 }
 
-std::atomic<int> g_attr_set[8][64];  // per variant and device: dynamic-LDS limit raised once, not per call
+std::atomic<int> g_attr_set[9][64];  // per variant and device: dynamic-LDS limit raised once, not per call
 
-template <int kWaves, int kSegs, bool kAcquire>
+template <int kWaves, int kSegs, bool kAcquire, bool kList = false>
 hipError_t launch(const Params &p, dim3 grid, void *stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kWaves == 1 ? 5 : kSegs == 8 ? 6 + kAcquire : kAcquire ? 4 : (kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
+    std::atomic<int> *flag = (dev >= 0 && dev < 64) ? &g_attr_set[kList ? 8 : kWaves == 1 ? 5 : kSegs == 8 ? 6 + kAcquire : kAcquire ? 4 : (kWaves == 8) * 2 + (kSegs > 2)][dev] : nullptr;
     if (!flag || !flag->load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs, kAcquire>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs, kAcquire, kList>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(kWaves, kSegs));
         if (e != hipSuccess) return e;
         if (flag) flag->store(1, std::memory_order_release);
@@ -696,7 +805,7 @@ hipError_t launch(const Params &p, dim3 grid, void *stream) {
     // hipLaunchKernel returns this launch's own status: an error left behind by an unrelated earlier HIP call on
     // this thread is neither reported as ours nor cleared (hipGetLastError would do both)
     void *args[] = {const_cast<Params *>(&p)};
-    return hipLaunchKernel(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs, kAcquire>), grid, dim3(kWaves * 64), args,
+    return hipLaunchKernel(reinterpret_cast<const void *>(cmhsa_fwd_kernel<kWaves, kSegs, kAcquire, kList>), grid, dim3(kWaves * 64), args,
                            lds_bytes(kWaves, kSegs), static_cast<hipStream_t>(stream));
 }
 
@@ -898,6 +1007,10 @@ int forward(const float *q, const float *k, const float *v, float *o,
     p.parts_per_bh = plan.parts_per_bh;
     p.splits_per_bh = plan.splits_per_bh;
     if (plan.use_table) memcpy(p.seg_table, plan.table, sizeof(unsigned) * (size_t)plan.n_wgs * 2 * plan.segs);
+    p.list_p = plan.list_p;
+    p.list_rev_max = plan.list_rev_max;
+    p.list_periods = plan.list_p ? (int)((bh + plan.list_p - 1) / plan.list_p) : 0;
+    if (plan.list_p) memcpy(p.seg_table, plan.table, sizeof(unsigned) * (size_t)plan.list_q * 8);
 
     // The hand-off of a split block without an acquire (sc1 stores, drained, one counter add, sc1 loads: MI355X guide,
     // visibility table row 1) is measured for ONE workgroup per CU.  That holds by the LDS footprint of the 8-wave table
@@ -905,7 +1018,8 @@ int forward(const float *q, const float *k, const float *v, float *o,
     // (another device, another LDS size) the merging workgroup runs the agent-scope acquire after all.
     if (split && !acquire) acquire = !one_workgroup_per_cu(dev, plan.segs == 8);
     hipError_t e;
-    if (waves == 1) e = launch<1, 2, false>(p, grid, stream);
+    if (plan.list_p) e = launch<1, 2, false, true>(p, grid, stream);
+    else if (waves == 1) e = launch<1, 2, false>(p, grid, stream);
     else if (!p.use_table) e = waves == 8 ? launch<8, 2, false>(p, grid, stream) : launch<4, 2, false>(p, grid, stream);
     else if (waves == 4) e = launch<4, 4, false>(p, grid, stream);
     else if (plan.segs == 8) e = split && acquire ? launch<8, 8, true>(p, grid, stream) : launch<8, 8, false>(p, grid, stream);
@@ -984,6 +1098,13 @@ int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspac
                  (long long)bh, cus, pl.t16.blocks, pl.t16.tiles_per_simd, pl.t16.max_jobs, pl.t16.contig ? "XCD-contiguous" : "2-D", pl.cycles);
         return CMHSA_OK;
     }
+    if (pl.list_p) {
+        const long long periods = (long long)((bh + pl.list_p - 1) / pl.list_p);
+        snprintf(buf, (size_t)buf_len, "%s: 1-wave workgroups, %d lists per period of %d (b,h) x %lld periods on %d CUs, %d query blocks per "
+                 "(b,h), at most %d units and %d jobs per list, workspace 0 B, estimate %.0f cycles", pl.family, pl.list_q, pl.list_p, periods,
+                 cus, (int)nqb, pl.list_units, pl.list_jobs, pl.cycles);
+        return CMHSA_OK;
+    }
     int n = snprintf(buf, (size_t)buf_len, "%s: %d-wave workgroups, %d per (b,h) x %lld (b,h) on %d CUs, chain cap %d, SIMD cap %d, "
                      "%d of %lld query blocks per (b,h) split across workgroups, workspace %zu B, estimate %.0f cycles",
                      pl.family, pl.pp.waves, pl.pp.wgs_per_bh, (long long)bh, cus, pl.pp.chain, pl.simd_cap, pl.splits_per_bh,
@@ -1022,6 +1143,19 @@ int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, i
     dim3 grid;
     const int grid_rc = plan_grid(plan, bh, grid);
     if (grid_rc != CMHSA_OK) return grid_rc;
+    if (plan.list_p) {
+        // job lists: header as below with out[2] = 0, out[8] = units of the longest list, out[10] = 3, out[12] = (b,h)s per
+        // period, out[13] = lists per period (= grid y), out[14] = jobs of the longest list, out[15] = blocks of at most that many units are taken in descending order;
+        // then 8 words per list as the
+        // kernel reads them (16 half-word entries: units | (b,h) within the period << 8; 0 = end)
+        const int64_t need_l = 16 + (int64_t)plan.list_q * 8;
+        if (!out || cap < need_l) return (int)need_l;
+        const int header_l[16] = {1, 2, 0, (int)grid.x, (int)grid.y, (int)grid.z, 0, 0, plan.list_units, (int)nqb, 3, 0,
+                                  plan.list_p, plan.list_q, plan.list_jobs, plan.list_rev_max};
+        memcpy(out, header_l, sizeof(header_l));
+        for (int i = 0; i < plan.list_q * 8; ++i) out[16 + i] = (int)plan.table[i];
+        return (int)need_l;
+    }
     const int segs = plan.use_table ? plan.segs : 2;
     const int64_t need = 16 + (int64_t)plan.pp.wgs_per_bh * segs * 5;
     if (need > 0x7fffffffLL) return CMHSA_ERR_TOO_LARGE;

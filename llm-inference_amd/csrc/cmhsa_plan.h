@@ -52,6 +52,9 @@ struct Plan {
     const char *family = "analytic";
     int segs = 4;                                // table plans: segments per workgroup record (4 or 8)
     unsigned table[kTableSize];                  // table plans: Params::seg_table
+    int list_p = 0, list_q = 0;                  // > 0: job lists (one-wave workgroups): a period of list_p (b,h)s on list_q waves; table = the lists
+    int list_units = 0, list_jobs = 0;           //      units / jobs of the longest list
+    int list_rev_max = 0;                        //      blocks of at most this many units are taken in descending order
     bool tiles16 = false;                        // the 16-row-block family (cmhsa_fwd16.hip): everything above but cycles / family is unused
     cmhsa_t16::Plan16 t16;
 };
@@ -402,6 +405,138 @@ int device_cu_count(int dev) {
     return n;
 }
 
+// ---- job lists (the kernel's kList variant): one-wave workgroups that each run a list of whole query blocks of several
+// (b,h)s.  A PERIOD of p consecutive (b,h)s is dealt to q lists (waves); every period uses the same lists, so the table
+// is q x 16 half-word entries whatever B*H is.  q = wave slots (x rounds) / periods, so that the launch is one round (or
+// a whole number of rounds) of waves that all carry (almost) the same number of units.
+//   schedule 1 ("teams"): the lists form teams of nqb; a team takes TWO (b,h)s A and B at a time.  With h = nqb / 2, the
+//       blocks of more than h units are "long", the others "short".  Waves 0 .. h-1: A's long block nqb-i, then B's short
+//       block i+1; the other waves: B's long block, then A's short block (an odd nqb's middle blocks of A and B share one
+//       wave) -- nqb+1 units for everyone.  Long blocks START together and are streamed in ascending order, short blocks END
+//       together and are streamed in DESCENDING order (the kernel's list_rev_max = h): either way the waves on one (b,h)
+//       read the same K / V unit at the same time (L2 hits for all but one; measured: 482 -> 461 us at B64 H25 T512 against
+//       every block ascending).  The order depends on the block's length only, never on its place in a list.
+//       The last few (b,h)s of the period are dealt block by
+//       block, longest first, to the least loaded list, which evens out the ends;
+//   schedule 0: every (b,h) in turn, longest block first, to the least loaded list; the last `tail` (b,h)s pooled as above.
+struct ListSchedule { int max_units = 0, max_jobs = 0; unsigned short e[64][16]; int len[64], load[64]; };
+
+bool list_schedule(ListSchedule &ls, int p, int q, int nqb, int sched, int tail) {
+    for (int l = 0; l < q; ++l) { ls.len[l] = 0; ls.load[l] = 0; }
+    auto put = [&](int l, int bh_i, int n) {
+        if (ls.len[l] >= 16) return false;
+        ls.e[l][ls.len[l]++] = (unsigned short)(n | (bh_i << 8));
+        ls.load[l] += n;
+        return true;
+    };
+    auto least = [&]() {
+        int best = -1;
+        for (int l = 0; l < q; ++l)
+            if (ls.len[l] < 16 && (best < 0 || ls.load[l] < ls.load[best])) best = l;
+        return best;
+    };
+    int next_bh = 0;
+    if (sched == 1) {
+        const int teams = q / nqb;
+        if (teams < 1) return false;
+        const int want_tail = max(1, (q * 5 / 2 + nqb - 1) / nqb);       // blocks enough for the pooled tail to even out the ends
+        const int phases = max(0, (p - want_tail) / (2 * teams));
+        const int h = nqb / 2;
+        for (int k = 0; k < phases; ++k)
+            for (int t = 0; t < teams; ++t) {
+                const int a = next_bh, b = next_bh + 1, l0 = t * nqb;
+                for (int i = 0; i < h; ++i) {
+                    if (!put(l0 + i, a, nqb - i) || !put(l0 + i, b, i + 1)) return false;                       // A long, B short
+                    if (!put(l0 + nqb - h + i, b, nqb - i) || !put(l0 + nqb - h + i, a, i + 1)) return false;   // B long, A short
+                }
+                if (nqb & 1)
+                    if (!put(l0 + h, a, h + 1) || !put(l0 + h, b, h + 1)) return false;                         // both middle blocks
+                next_bh += 2;
+            }
+        tail = p - next_bh;
+    }
+    tail = min(tail, p - next_bh);
+    for (; next_bh < p - tail; ++next_bh)
+        for (int n = nqb; n >= 1; --n) {
+            const int l = least();
+            if (l < 0 || !put(l, next_bh, n)) return false;
+        }
+    for (int n = nqb; n >= 1; --n)
+        for (int b = next_bh; b < p; ++b) {
+            const int l = least();
+            if (l < 0 || !put(l, b, n)) return false;
+        }
+    ls.max_units = ls.max_jobs = 0;
+    for (int l = 0; l < q; ++l) { ls.max_units = max(ls.max_units, ls.load[l]); ls.max_jobs = max(ls.max_jobs, ls.len[l]); }
+    return true;
+}
+
+// cycles of a launch of job lists (at the 2.4 GHz the other estimates assume): R rounds of waves, two per SIMD, 9.1 k cycles
+// per unit and wave, 7 k per block (its boundary is ~150 VALU instructions that each wait for a gap in the SIMD partner's
+// MFMA stream, and its first unit takes the max path), one prologue per wave.  Fit to B = 16..64, H = 12 / 25, T = 256..1024
+// (profiles/r03_experiments/job_lists_vs_pairs.log), within 3 % where the family is picked.
+double list_cycles(int rounds, int max_units, int max_jobs) { return rounds * (16000.0 + 9100.0 * max_units + 7000.0 * max_jobs); }
+
+bool list_plan(Plan &out, int64_t bh, int nqb, int cus, int forced_sched, int forced_p) {
+    static const bool list_rev = env_int("CMHSA_LIST_REV", 1) != 0;     // (experiments: 0 = every block in ascending order)
+    if (nqb < 2 || nqb > 64 || bh < 8 || cus < 1) return false;
+    const int64_t slots = 8LL * cus, jobs = bh * nqb, units_per_bh = (int64_t)nqb * (nqb + 1) / 2;
+    const int64_t rounds = max((int64_t)1, (jobs + 13 * slots - 1) / (13 * slots));      // <= 13 jobs per list on average (16 fit)
+    const int64_t waves_target = rounds * slots;
+    if (bh * units_per_bh < waves_target * (3 * nqb / 2)) return false;                  // lists too short for whole blocks to balance
+    if (rounds > 64) return false;
+    // candidates: period lengths whose ideal mean list load is lowest (waves are only lost to q = floor(...))
+    struct Cand { int p, q; double mean; };
+    Cand cands[64];
+    int n_cands = 0;
+    for (int p = 1; p <= 64 && p <= bh; ++p) {
+        if (forced_p > 0 && p != forced_p) continue;
+        const int64_t periods = (bh + p - 1) / p;
+        const int q = (int)min((int64_t)64, waves_target / periods);
+        if (q < 1 || p * nqb > 14 * q) continue;
+        cands[n_cands++] = Cand{p, q, (double)p * units_per_bh / q};
+    }
+    if (!n_cands) return false;
+    std::sort(cands, cands + n_cands, [](const Cand &a, const Cand &b) { return a.mean < b.mean || (a.mean == b.mean && a.p < b.p); });
+    bool have = false;
+    ListSchedule best, ls;
+    int best_p = 0, best_q = 0;
+    double best_cycles = 0.0;
+    for (int ci = 0; ci < n_cands && ci < 6; ++ci) {
+        const int p = cands[ci].p, q = cands[ci].q;
+        for (int sched = 1; sched >= 0; --sched) {
+            if (forced_sched >= 0 ? sched != forced_sched : sched == 0) continue;     // (schedule 0 scatters a (b,h)'s blocks in time: 691 against 470 us at B64 H25 T512)
+            for (int tail = 0; tail <= (sched ? 0 : 8); tail += 2) {
+                int qq = q;
+                if (sched == 1) qq = q / nqb * nqb;                      // whole teams
+                if (qq < 1 || !list_schedule(ls, p, qq, nqb, sched, tail)) continue;
+                const int64_t periods = (bh + p - 1) / p;
+                const int r = (int)((periods * qq + slots - 1) / slots);
+                const double c = list_cycles(r, ls.max_units, ls.max_jobs);
+                if (!have || c < best_cycles) { best = ls; best_p = p; best_q = qq; best_cycles = c; have = true; }
+            }
+        }
+    }
+    if (!have) return false;
+    out = Plan();
+    out.pp = pack_plan(nqb, 1);
+    out.pp.wgs_per_bh = out.n_wgs = 0;
+    out.use_table = false;
+    out.list_p = best_p;
+    out.list_q = best_q;
+    out.list_units = best.max_units;
+    out.list_jobs = best.max_jobs;
+    out.list_rev_max = list_rev ? nqb / 2 : 0;
+    const int64_t periods = (bh + best_p - 1) / best_p;
+    out.cycles = list_cycles((int)((periods * best_q + slots - 1) / slots), best.max_units, best.max_jobs);
+    out.family = "job lists, one wave per list";
+    memset(out.table, 0, sizeof(out.table));
+    for (int l = 0; l < best_q; ++l)
+        for (int i = 0; i < best.len[l]; ++i) out.table[l * 8 + i / 2] |= (unsigned)best.e[l][i] << (16 * (i & 1));
+    return true;
+}
+
+
 Plan choose_plan(int64_t bh, int nqb, int seq_len_hint, int cus, bool allow_split) {
     static const int forced_waves = env_int("CMHSA_WAVES", 0);
     static const int forced_chain = env_int("CMHSA_CHAIN", 0);
@@ -534,6 +669,18 @@ Plan choose_plan(int64_t bh, int nqb, int seq_len_hint, int cus, bool allow_spli
             have = true;
         }
     }
+    //   (e) job lists: one-wave workgroups, each a list of whole blocks of several (b,h)s, ONE round of equally long waves
+    //       (list_plan() above).  Many (b,h)s of short sequences: B=64 H=25 T=512 is 6.25 rounds of wave pairs.
+    {
+        static const int forced_list = env_int("CMHSA_LIST", -1);       // -1 = planner's choice, 0 = never, 1 = wherever it applies
+        static const int forced_sched = env_int("CMHSA_LIST_SCHED", -1), forced_p = env_int("CMHSA_LIST_P", 0);
+        Plan lp;
+        if (forced_list != 0 && multi_ok && forced_waves <= 1 && forced_lpt < 0 && bh <= 0x7fffffff / 64 &&
+            list_plan(lp, bh, nqb, cus, forced_sched, forced_p) && (forced_list == 1 || lp.cycles < best.cycles * 0.97)) {
+            best = lp;
+            have = true;
+        }
+    }
     //   (d) 16-row blocks on v_mfma_f32_16x16x4_f32 (cmhsa_fwd16.hip): four-wave workgroups, one per CU, every wave a list
     //       of jobs cut so that all SIMDs carry the same number of 16 x 16 tiles; no LDS staging, no prologue barrier.
     //       Grids of one round (bh <= CUs, T <= 4080): a quarter of the 32 x 32 unit's quantum and half its fixed cost.
@@ -597,6 +744,12 @@ size_t plan_workspace_bytes(const Plan &pl, int64_t bh) {
 // y = block, longest first, z = group.  HIP limits: y, z <= 65535, and x * threads < 2^32.
 int plan_grid(const Plan &plan, int64_t bh, dim3 &grid) {
     const PackPlan &pl = plan.pp;
+    if (plan.list_p) {                               // job lists: x = XCD, y = list, z = period / 8
+        const int64_t periods = (bh + plan.list_p - 1) / plan.list_p, z = (periods + 7) / 8;
+        if (z > 65535) return CMHSA_ERR_TOO_LARGE;
+        grid = dim3(8u, (unsigned)plan.list_q, (unsigned)z);
+        return CMHSA_OK;
+    }
     const bool xcd_map = bh % 8 == 0 && bh / 8 <= 65535 && !plan.longest_first;
     const int64_t lf_groups = plan.longest_first ? (bh + plan.longest_first - 1) / plan.longest_first : 0;
     if (lf_groups > 65535) return CMHSA_ERR_TOO_LARGE;

@@ -361,6 +361,83 @@ def test_one_wave_workgroup_plans(B, H, T, family, gpu_device):
     assert torch.equal(cmhsa.attention_fwd(q, k, v, H), out)          # and again: bit-reproducible
 
 
+LISTS = "job lists, one wave per list"
+
+
+@pytest.mark.parametrize("B,H,T", [(32, 25, 512), (37, 25, 511), (64, 25, 256), (64, 25, 500)])
+def test_job_list_plans(B, H, T, gpu_device):
+    """Many (b,h)s of short sequences (config 4's attention shapes) run as ONE round of one-wave workgroups that each work
+    through a list of whole query blocks of several (b,h)s (a period of 25-29 (b,h)s dealt to 32 or 64 lists; blocks of
+    up to nqb / 2 units taken from the diagonal down, wherever they are).  (b,h) counts that are and are not a multiple of the period
+    (37 * 25 = 31 periods of 29 + 26), exact and ragged lengths: every element written, the whole output against the oracle's
+    formula in float64, batch rows of equal inputs bit-identical, packed-QKV strides, bit-reproducible."""
+    assert cmhsa.plan_description(B, T, H).startswith(LISTS + ":"), cmhsa.plan_description(B, T, H)
+    torch.manual_seed(B * 1000 + T)
+    d = 64 * H
+    qkv = torch.randn(B, T, 3 * d, device=gpu_device)
+    qkv[:, T // 2:, d:2 * d] *= 3.0                                # later keys score higher: the running max moves inside a block
+    qkv[B - 1] = qkv[0]
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    out = torch.full((B, T, d), float("nan"), device=gpu_device)
+    cmhsa.attention_fwd(q, k, v, H, out=out)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out[0], out[B - 1])
+    for b0 in range(0, B, 8):                                     # (float64 scores of 8 batch rows at a time: memory)
+        sl = slice(b0, min(B, b0 + 8))
+        want = oracle.naive_attention_torch(q[sl].double(), k[sl].double(), v[sl].double(), H)
+        assert (out[sl].double() - want).abs().max().item() <= TOL, b0
+    assert torch.equal(cmhsa.attention_fwd(q, k, v, H), out)          # and again: bit-reproducible
+    assert torch.equal(cmhsa.attention_fwd_packed_qkv(qkv, H), out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"CMHSA_LIST": "1"}, {"CMHSA_LIST": "1", "CMHSA_LIST_REV": "0"}, {"CMHSA_LIST": "1", "CMHSA_LIST_SCHED": "0"},
+                                 {"CMHSA_LIST": "1", "CMHSA_LIST_P": "7"}, {"CMHSA_LIST": "0"}])
+def test_forced_job_lists_in_a_child_process(env):
+    """The job-list family wherever it applies (plan-forcing test build, as in test_forced_plans_in_a_child_process): both
+    schedules, with and without descending short blocks, a forced period length, and switched off; (b,h) counts that leave a short
+    last period, one-unit blocks (two levels of look-ahead across block boundaries), a single (b,h) per period."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%r, %r]
+import cmhsa
+cmhsa.LIB_PATH = %r
+from oracle import naive_attention as oracle
+rng = np.random.default_rng(78)
+worst, on_lists = 0.0, 0
+for B, T, H in ((100, 300, 7), (333, 200, 3), (41, 777, 16), (16, 512, 25), (1000, 480, 1), (64, 65, 25), (64, 128, 25), (9, 1024, 12), (203, 100, 5)):
+    d = 64 * H
+    qkv = rng.standard_normal((B, T, 3 * d), dtype=np.float32)
+    qkv[:, T // 2:, d:2 * d] *= 4.0
+    t = torch.from_numpy(qkv).cuda()
+    on_lists += cmhsa.plan_description(B, T, H).startswith("job lists")
+    out = torch.full((B, T, d), float("nan"), device="cuda")
+    cmhsa.attention_fwd(t[..., :d], t[..., d:2 * d], t[..., 2 * d:], H, out=out)
+    assert torch.isfinite(out).all(), (B, T, H)           # every element written
+    split = lambda x: x.reshape(B, T, H, 64).transpose(1, 2)
+    with torch.nn.attention.sdpa_kernel(torch.nn.attention.SDPBackend.MATH):   # every (b,h), fp32: a wrong base or a dropped job shows
+        ref = torch.nn.functional.scaled_dot_product_attention(split(t[..., :d]), split(t[..., d:2 * d]), split(t[..., 2 * d:]), is_causal=True)
+    assert (out - ref.transpose(1, 2).reshape(B, T, d)).abs().max().item() <= 3e-4, (B, T, H)
+    out = out.cpu().numpy()
+    for b in sorted({0, B // 2, B - 1}):                  # and sampled (b,h)s against the f64 oracle at the parity bound
+        for h in sorted({0, H - 1}):
+            sl = slice(64 * h, 64 * h + 64)
+            want = oracle.naive_attention_f64(qkv[b, :, sl], qkv[b, :, d + 64 * h:d + 64 * h + 64], qkv[b, :, 2 * d + 64 * h:2 * d + 64 * h + 64], 1)
+            worst = max(worst, float(np.abs(out[b, :, sl] - want).max()))
+print("WORST", worst, "ON_LISTS", on_lists)
+assert worst <= 1e-4
+""" % (root, os.path.join(root, "llm-inference_amd"), os.path.join(root, "tests", "helpers", "libcmhsa_hip_planenv.so"))
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    n = int(r.stdout.split("ON_LISTS")[1].split()[0])
+    assert (n >= 5) if env["CMHSA_LIST"] == "1" else (n == 0), r.stdout[-500:]
+
+
 @pytest.mark.gpu
 def test_packed_qkv_entry_point_equals_the_three_view_call(gpu_device):
     """one packed (.., T, 3*d_model) buffer in -- same kernel, so the same bits as slicing it into

@@ -79,9 +79,39 @@ def check_tiles16_plan(plan, B, T, H, cus):
     return plan
 
 
+def check_list_plan(plan, B, T, H, cus):
+    """Job lists (one-wave workgroups that run a list of whole blocks of several (b,h)s): every period of `period_bh`
+    consecutive (b,h)s uses the same `lists_per_period` lists; per period every block n = 1..nqb of every (b,h) of it on
+    exactly one list; at most 16 jobs per list; the grid (8, lists, ceil(periods / 8)) covers every period; a short last
+    period keeps every block of the (b,h)s it has (the kernel drops the entries of the others)."""
+    tag = (B, T, H, cus)
+    nqb, bh = (T + 31) // 32, B * H
+    p, q = plan["period_bh"], plan["lists_per_period"]
+    assert plan["waves"] == 1 and plan["nqb"] == nqb and plan["workspace_256"] == 0 and plan["parts_per_bh"] == 0, tag
+    assert 1 <= p <= 255 and 1 <= q <= 64 and len(plan["lists"]) == q, tag
+    periods = (bh + p - 1) // p
+    assert plan["grid_x"] == 8 and plan["grid_y"] == q and plan["grid_z"] == (periods + 7) // 8 <= 65535, tag
+    seen = {}
+    for l, jobs in enumerate(plan["lists"]):
+        assert 1 <= len(jobs) <= 16 == len(plan["raw_words"][l]) * 2, (tag, l)
+        assert len(jobs) <= plan["jobs_per_list"] and sum(n for n, _ in jobs) <= plan["units_per_list"], (tag, l)
+        for n, b in jobs:
+            assert 1 <= n <= nqb and 0 <= b < p and (b, n) not in seen, (tag, l, n, b)
+            seen[(b, n)] = l
+        es = [(w >> (16 * h)) & 0xffff for w in plan["raw_words"][l] for h in (0, 1)]
+        assert all(e == 0 for e in es[len(jobs):]), (tag, l)                     # packed at the front, zero behind
+    assert len(seen) == p * nqb, tag                                              # every block of every (b,h) of a period
+    assert plan["descending_up_to"] in (0, nqb // 2), tag
+    # one round (or a whole number of rounds) of equally long waves: the longest list is within two blocks of the mean
+    assert plan["units_per_list"] <= p * nqb * (nqb + 1) / 2 / q + nqb, tag
+    return plan
+
+
 def check_plan(B, T, H, with_ws, cus):
     plan = cmhsa.plan_dump(B, T, H, with_ws, cus)
     tag = (B, T, H, with_ws, cus)
+    if plan["family"] == "lists":
+        return check_list_plan(plan, B, T, H, cus)
     if plan["family"] == "tiles16":
         assert plan["workspace_256"] == 0 and plan["parts_per_bh"] == 0, tag
         return check_tiles16_plan(plan, B, T, H, cus)
@@ -174,15 +204,15 @@ def test_every_plan_covers_every_unit_once(with_ws):
             continue
         plan = check_plan(B, T, H, with_ws, 256)
         count += 1
-        if plan["family"] == "tiles16":
-            families.add("tiles16")
+        if plan["family"] in ("tiles16", "lists"):
+            families.add(plan["family"])
             continue
         families.add((plan["waves"], plan["use_table"], bool(plan["longest_first"]), bool(plan["parts_per_bh"])))
     assert count > 400
     # the sweep reaches every family: analytic 4 / 8 waves, tables, split tables (with a workspace), both one-wave forms
     assert {(4, 0, False, False), (8, 0, False, False), (1, 0, False, False), (1, 0, True, False)} <= families
-    assert "tiles16" in families
-    families.discard("tiles16")
+    assert "tiles16" in families and "lists" in families
+    families -= {"tiles16", "lists"}
     assert any(t for _, t, _, _ in families)
     if with_ws:
         assert any(p for _, _, _, p in families)
@@ -239,8 +269,8 @@ def test_baseline_configs_pick_the_documented_families():
     for B, H in ((32, 2), (32, 16)):                              # config 5: one GPU's shard, and whole
         c5 = cmhsa.plan_dump(B, 4096, H, True, 256)
         assert c5["waves"] == 1 and not c5["longest_first"] and c5["wgs_per_bh"] == 64
-    c4 = cmhsa.plan_dump(64, 512, 25, True, 256)                   # config 4's attention shape on one GPU
-    assert c4["waves"] == 1 and not c4["longest_first"]
+    c4 = cmhsa.plan_dump(64, 512, 25, True, 256)                   # config 4's attention shape on one GPU: one round of job lists
+    assert c4["family"] == "lists" and c4["period_bh"] == 25 and c4["lists_per_period"] == 32 and c4["units_per_list"] <= 110
     mid = cmhsa.plan_dump(16, 1024, 12, True, 256)                 # 1.5 rounds of pairs -> longest first
     assert mid["waves"] == 1 and mid["longest_first"] == 192
 
