@@ -93,7 +93,8 @@ int cmhsa_fp32_fwd_ws(const float *q, const float *k, const float *v, float *o,
  * It is cmhsa_fp32_fwd_ws with the workspace taken from a static array in device memory that the library's code
  * object carries: CMHSA_NOALLOC_SCRATCH_BYTES (1 MiB) on every GPU the library runs on, held until the process ends.
  * The call allocates nothing (no hipMalloc / hipFree, no allocating library routine); the array's address on the
- * current device is looked up once per device (hipGetSymbolAddress, at the first call on that device).
+ * current device is looked up once per device (hipGetSymbolAddress, at the first call on that device: a host-side
+ * query, not a stream operation -- make a device's first call outside graph capture, as with any set-up).
  *   - A shape whose plan needs more scratch than the array holds is rejected with CMHSA_ERR_WORKSPACE (nothing is
  *     launched); cmhsa_fp32_fwd_workspace_bytes() tells the need in advance.  BASELINE config 2 needs 0.8 MiB.
  *   - Every call on a GPU shares that GPU's array: calls that OVERLAP in time on one GPU (different streams) race.
@@ -130,7 +131,20 @@ int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspac
  *               first unit | unit count | wave mask | part word (0 = whole block, else first part slot | part index << 8 |
  *               parts << 12 | split id << 16).
  * The waves of a segment's mask take its units round-robin in ascending wave order; one-wave workgroups run their
- * segments one after the other, whole. */
+ * segments one after the other, whole.
+ * Two families have layouts of their own, told by out[10]:
+ *   out[10] == 2, the 16-key-tile kernel (grids of one round): out[0] waves per workgroup (4 or 8) | out[1] job words per
+ *               wave (32 / waves) | out[2] workgroups per (b,h) | out[3..5] grid | out[8] tiles on the busiest SIMD |
+ *               out[9] query blocks | out[12] 16-row halves per block (1 or 2) | out[13] XCD-contiguous 1-D grid?; then per
+ *               workgroup and per job list in run order its job words: block | first tile << 8 | tiles << 16 | rank of the
+ *               piece << 24 | pieces of the block << 27 | (first word of a list) the workgroup merges << 31; tiles == 0 =
+ *               no job.  Tile t of block b covers keys [16 t, 16 t + 16), block b the query rows [16 s b, 16 s (b + 1)),
+ *               s = out[12].
+ *   out[10] == 3, job lists (one-wave workgroups that run whole blocks of several (b,h)s): out[3..5] grid = (8, lists,
+ *               ceil(periods / 8)) | out[8] units of the longest list | out[9] query blocks | out[12] (b,h)s per period |
+ *               out[13] lists per period | out[14] jobs of the longest list | out[15] blocks of at most that many units are
+ *               taken from the diagonal unit down; then 8 words per list = 16 half-word entries: units of the block |
+ *               (b,h) within the period << 8; 0 = end.  Period P holds the (b,h)s [P out[12], (P + 1) out[12]) that exist. */
 int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, int cus, int *out, int cap);
 
 /* Convenience form of the reference's exact contract: 2-D (N, d_model) tensors, batch 1

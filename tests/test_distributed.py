@@ -200,6 +200,27 @@ def test_bench_self_launch_fails_fast_when_a_rank_has_no_gpu():
     assert "has no GPU" in r.stderr and "child ranks exited" in r.stderr
 
 
+@pytest.mark.gpu
+def test_bench_rank_gives_up_when_the_other_rank_never_arrives():
+    """One rank of a world of two, started the way torch.distributed.run would start it, the other never started: with
+    --rendezvous-timeout the rank must leave the rendezvous with an error within seconds (torch's default is 10-30
+    minutes, during which a driver would see a hung job)."""
+    import socket
+    import subprocess
+    import time
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {**os.environ, "WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+           "CMHSA_BENCH_BACKEND": "gloo"}
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rendezvous-timeout", "6"],
+                       capture_output=True, text=True, env=env, timeout=150)
+    assert r.returncode != 0 and time.perf_counter() - t0 < 90, r.stderr[-2000:]
+    assert "{" not in r.stdout                                  # no result line from a rank that never met its peer
+
+
 def test_bench_self_launch_relays_child_failure_on_a_box_without_gpu():
     """No WORLD_SIZE in the environment and --gpus 2: the parent starts two ranks and must itself stay off the GPU.
     On a CPU-only box the ranks exit with "needs a GPU"; the parent reports it and exits non-zero.  (On the GPU box the

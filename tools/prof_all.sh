@@ -24,13 +24,18 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OU
 step "rocprofv3 kernel trace of tools/cmhsa_bench (config 2 from a cold device, config-5 shard)"
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_config2" -- "$ROOT/tools/cmhsa_bench" 1 12 1024 4000 4000 > "$OUT/trace_config2.log" 2>&1 || fail trace_config2
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_config5_shard" -- "$ROOT/tools/cmhsa_bench" 32 2 4096 50 10 > "$OUT/trace_config5_shard.log" 2>&1 || fail trace_config5_shard
+step "rocprofv3 kernel trace: the B = 1 launches of a generation (config 3: 16-key-tile kernel) and config 4's attention shape (job lists)"
+for CFG in "config3_t128 1 12 128 4000 4000" "config3_t256 1 12 256 4000 4000" "config3_t512 1 12 512 4000 4000" "config4_shape 64 25 512 300 2000"; do
+  set -- $CFG
+  timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$1" -- "$ROOT/tools/cmhsa_bench" $2 $3 $4 $5 $6 > "$OUT/trace_$1.log" 2>&1 || fail trace_$1
+done
 
 # counter passes: one --pmc pass per run (rocprofv3 does not split counters), --pmc never combined with a trace
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VMEM_RD"
 P3="FETCH_SIZE"
 P4="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
-for CFG in "config2 1 12 1024 50" "config5_shard 32 2 4096 10"; do
+for CFG in "config2 1 12 1024 50" "config5_shard 32 2 4096 10" "config3_t256 1 12 256 50" "config4_shape 64 25 512 10"; do
   set -- $CFG
   TAG=$1
   step "rocprofv3 --pmc passes, $TAG"
