@@ -135,7 +135,8 @@ int cmhsa_plan_describe(int batch, int seq_len, int num_heads, int with_workspac
  * Two families have layouts of their own, told by out[10]:
  *   out[10] == 2, the 16-key-tile kernel (grids of one round): out[0] waves per workgroup (4 or 8) | out[1] job words per
  *               wave (32 / waves) | out[2] workgroups per (b,h) | out[3..5] grid | out[8] tiles on the busiest SIMD |
- *               out[9] query blocks | out[12] 16-row halves per block (1 or 2) | out[13] XCD-contiguous 1-D grid?; then per
+ *               out[9] query blocks | out[12] 16-row halves per block (1 or 2) | out[13] XCD-contiguous 1-D grid? | out[14]
+ *               granule g (first tile and tiles of a job word count g tiles each: 1, or 2 beyond T = 4080); then per
  *               workgroup and per job list in run order its job words: block | first tile << 8 | tiles << 16 | rank of the
  *               piece << 24 | pieces of the block << 27 | (first word of a list) the workgroup merges << 31; tiles == 0 =
  *               no job.  Tile t of block b covers keys [16 t, 16 t + 16), block b the query rows [16 s b, 16 s (b + 1)),

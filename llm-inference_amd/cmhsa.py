@@ -169,7 +169,9 @@ def plan_dump(batch: int, seq_len: int, num_heads: int, with_workspace: bool = F
         plan.update(family="tiles16", jobs_per_wave=J, blocks=plan["nqb"], tiles_per_simd=plan["simd_cap"], sub=plan["chain"],
                     contig=bool(plan["n_paired"]))
         words = [[[buf[16 + (j * W + w) * J + i] & 0xffffffff for i in range(J)] for w in range(W)] for j in range(plan["wgs_per_bh"])]
-        plan["workgroups"] = [[[(x & 255, (x >> 8) & 255, (x >> 16) & 255, (x >> 24) & 7, (x >> 27) & 15) for x in wave if (x >> 16) & 255]
+        gran = max(1, plan["n_alone"])                     # tiles per count of a job word's first-tile / tiles fields
+        plan["granule"] = gran
+        plan["workgroups"] = [[[(x & 255, gran * ((x >> 8) & 255), gran * ((x >> 16) & 255), (x >> 24) & 7, (x >> 27) & 15) for x in wave if (x >> 16) & 255]
                                for wave in wg] for wg in words]
         plan["merges"] = [[bool(wave[0] >> 31) for wave in wg] for wg in words]
         plan["raw_words"] = words

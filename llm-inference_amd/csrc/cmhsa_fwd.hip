@@ -1128,14 +1128,14 @@ int cmhsa_plan_dump(int batch, int seq_len, int num_heads, int with_workspace, i
     const Plan plan = cached_plan(bh, seq_len, cus, with_workspace != 0);
     if (plan.tiles16) {
         // the 16-key-tile family: header as below with out[1] = job words per wave, out[8] = tiles on the busiest SIMD,
-        // out[9] = query blocks, out[10] = 2, out[12] = 16-row halves per block, out[13] = XCD-contiguous grid; then, per
+        // out[9] = query blocks, out[10] = 2, out[12] = 16-row halves per block, out[13] = XCD-contiguous grid, out[14] = tiles per count of a job word; then, per
         // workgroup of a (b,h) and per job list (run order), its job words as they are (cmhsa_tiles16.h)
         const cmhsa_t16::Plan16 &t = plan.t16;
         const int J = cmhsa_t16::kWordsPerWg / t.waves;
         const int64_t total = bh * t.wgs_per_bh, need16 = 16 + (int64_t)t.wgs_per_bh * cmhsa_t16::kWordsPerWg;
         if (!out || cap < need16) return (int)need16;
         const int header16[16] = {t.waves, J, t.wgs_per_bh, t.contig ? (int)((total + 7) / 8 * 8) : t.wgs_per_bh, t.contig ? 1 : (int)bh, 1, 0, 0,
-                                  t.tiles_per_simd, t.blocks, 2, 0, t.sub, t.contig ? 1 : 0, 0, 0};
+                                  t.tiles_per_simd, t.blocks, 2, 0, t.sub, t.contig ? 1 : 0, t.granule, 0};
         memcpy(out, header16, sizeof(header16));
         for (int64_t i = 0; i < need16 - 16; ++i) out[16 + i] = (int)t.table[i];
         return (int)need16;

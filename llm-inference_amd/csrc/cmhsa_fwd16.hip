@@ -63,6 +63,7 @@ struct Params16 {
     unsigned q_rs, k_rs, v_rs, o_rs;    // row strides (floats; <= 2^24, host check)
     int seq_len, num_heads;
     int wgs_per_bh, total_wgs, per_xcd; // workgroups per (b,h); bh * wgs_per_bh; ceil(total_wgs / 8)
+    int gshift;                         // a job word counts tiles in granules of 1 << gshift (Plan16::granule)
     unsigned heads_magic, wgs_magic;    // floor((2^32-1) / num_heads), / wgs_per_bh
     unsigned table[kTableWords];        // [workgroup of a (b,h)][list u][32 / waves] job words (cmhsa_tiles16.h)
 };
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fwd16_kernel(Params16 p) {
         asm volatile("" ::"s"(jw[4]), "s"(jw[5]), "s"(jw[6]), "s"(jw[7]));
     asm volatile("" ::"s"(jw[0]), "s"(jw[1]), "s"(jw[2]), "s"(jw[3]), "s"(p.q), "s"(p.k), "s"(p.v), "s"(p.o), "s"(p.q_rs), "s"(p.k_rs),
                  "s"(p.v_rs), "s"(p.o_rs));
-    asm volatile("" ::"s"(p.q_bs), "s"(p.k_bs), "s"(p.v_bs), "s"(p.o_bs), "s"(p.seq_len), "s"(p.num_heads), "s"(p.heads_magic));
+    asm volatile("" ::"s"(p.q_bs), "s"(p.k_bs), "s"(p.v_bs), "s"(p.o_bs), "s"(p.seq_len), "s"(p.num_heads), "s"(p.heads_magic), "s"(p.gshift));
     STAMP(124);
 
     const int b = udiv_magic(bh, p.num_heads, p.heads_magic), h = bh - b * p.num_heads;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fwd16_kernel(Params16 p) {
     // step's K (tile A, then B), then V
     {
         load_q(jw[0]);
-        const int row0 = (int)((jw[0] >> 8) & 255) * 16;
+        const int row0 = (int)(((jw[0] >> 8) & 255) << p.gshift) * 16;
         const bool en = njobs > 0;
         const __amdgpu_buffer_rsrc_t ks = rows_rsrc(kg, p.k_rs, row0, 32, N, en), vs = rows_rsrc(vg, p.v_rs, row0, 32, N, en);
 #pragma unroll
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fwd16_kernel(Params16 p) {
     STAMP(1);
     for (int ji = 0; ji < njobs; ++ji) {
         const unsigned cw = job(ji), nw = job(ji + 1);       // (lane kJobs holds "no job")
-        const int blk = cw & 255, lo = (cw >> 8) & 255, hi = lo + (int)((cw >> 16) & 255);
-        const int nlo = (nw >> 8) & 255;
+        const int blk = cw & 255, lo = (int)(((cw >> 8) & 255) << p.gshift), hi = lo + (int)(((cw >> 16) & 255) << p.gshift);
+        const int nlo = (int)(((nw >> 8) & 255) << p.gshift);
         const bool have_next = ((nw >> 16) & 255) != 0;
         float qf[kSub][16];          // Q^T fragments of the job, pre-scaled: k-step 4c + jj uses d = 16c + 4g + jj
 #pragma unroll
@@ -493,7 +494,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void fwd16_kernel(Params16 p) {
 // own measurements.  A job = query fragments, a first step down the max path, a store or an LDS image.
 constexpr double kFixedCycles = 9500.0, kJobCycles = 300.0;
 static double tiles_cost(int sub, int waves, int tiles, double kv_mb) {
-    if (sub == 2) return 2900.0 * tiles + (waves == 8 ? 2000.0 : 3000.0);
+    // 32-row blocks (a tile = 2 048 MFMA cycles): fits to single long prompts, B = 1..2, T = 1536..4000 (tools/run_t16_long.sh:
+    // 2.45 k cycles per tile with two waves per SIMD, 2.6 k with one, and a tail of 10-15 k in which a SIMD's younger wave, which
+    // loses the arbitration while both run, finishes alone); short grids come out above their measured times and are not picked
+    if (sub == 2) return waves == 8 ? 2450.0 * tiles + 10500.0 : 2600.0 * tiles + 15000.0;
     return (1300.0 + 250.0 * std::max(0.0, kv_mb - 3.0)) * tiles + (waves == 8 ? 2000.0 : 0.0);
 }
 
@@ -505,8 +509,18 @@ static double tiles_cost(int sub, int waves, int tiles, double kv_mb) {
 // q = ceil(load / 4) tiles, one per SIMD; with eight waves each run is halved between the SIMD's two waves.
 static bool build(int nblocks, int sub, int G, int waves, int method, double kv_mb, Plan16 &out) {
     const int J = kWordsPerWg / waves;
+    // share of a SIMD's run that its first-dispatched wave (even list) takes in an 8-wave workgroup.  With the static priority
+    // step of the kernel the YOUNGER wave wins the arbitration while both run; 40 : 60 lets them finish together on long runs
+    // (32-row blocks, B1 H12 T4096: 206.5 us at 50 : 50, 202.8 at 40 : 60, 208.3 at 24 : 76; tools/ab experiments, round 3)
+    const int older_pct = sub == 2 ? 40 : 50;
+    // a job word counts its tiles in 8 bits: blocks of more than 255 tiles (32-row blocks beyond T = 4080) are cut at even
+    // tile positions only -- every 32-row block has an even number of tiles, a step is two tiles -- and the words count pairs
+    const int gran = sub * nblocks > kMaxTiles ? 2 : 1;
+    if (gran == 2 && (sub != 2 || sub * nblocks > 2 * kMaxTiles)) return false;
     std::vector<std::vector<int>> bins;
     std::vector<int> load;
+    const bool mix = method >= 2;            // a workgroup's blocks laid out large, small, large, small, ... (below)
+    method &= 1;
     if (method == 0) {
         bins.assign((size_t)G, {});
         load.assign((size_t)G, 0);
@@ -546,6 +560,7 @@ static bool build(int nblocks, int sub, int G, int waves, int method, double kv_
     for (int j = 0; j < G; ++j) order[j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return load[a] > load[b2]; });
     out.sub = sub;
+    out.granule = gran;
     out.blocks = nblocks;
     out.wgs_per_bh = G;
     out.waves = waves;
@@ -554,7 +569,7 @@ static bool build(int nblocks, int sub, int G, int waves, int method, double kv_
     out.cycles = 0.0;
     std::fill(out.table, out.table + kTableWords, 0u);
     for (int jo = 0; jo < G; ++jo) {
-        const int j = order[jo], S = load[j], q = (S + 3) / 4;
+        const int j = order[jo], S = load[j], q = ((S + 3) / 4 + gran - 1) / gran * gran;
         out.tiles_per_simd = std::max(out.tiles_per_simd, q);
         // list boundaries in run order: bound[u] .. bound[u + 1]
         int bound[kMaxWaves + 1];
@@ -562,7 +577,8 @@ static bool build(int nblocks, int sub, int G, int waves, int method, double kv_
             const int a = std::min(S, sidx * q), e = std::min(S, (sidx + 1) * q);
             if (waves == 8) {
                 bound[2 * sidx] = a;
-                bound[2 * sidx + 1] = a + (e - a + 1) / 2;
+                // the older wave of the SIMD (even list) wins most arbitrations while both run: it takes the larger part
+                bound[2 * sidx + 1] = std::min(e, a + (((e - a) * older_pct + 99) / 100 + gran - 1) / gran * gran);
             } else {
                 bound[sidx] = a;
             }
@@ -571,7 +587,14 @@ static bool build(int nblocks, int sub, int G, int waves, int method, double kv_
         int njobs[kMaxWaves] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool merges = false;
         int pos = 0;
-        for (int b : bins[j]) {
+        // order of the blocks along the workgroup's line of tiles: longest first -- or, when that leaves some list with more
+        // jobs than its words (long sequences: the short blocks all end up on the last lists), alternately from both ends
+        std::vector<int> line = bins[j];
+        if (mix) {
+            const size_t nb = line.size();
+            for (size_t i = 0; i < nb; ++i) line[i] = (i & 1) ? bins[j][nb - 1 - i / 2] : bins[j][i / 2];
+        }
+        for (int b : line) {
             const int t = sub * b;
             // the lists [bound[u], bound[u+1]) that the block's tiles [pos, pos + t) meet
             int u_first = -1, u_last = -1;
@@ -585,7 +608,8 @@ static bool build(int nblocks, int sub, int G, int waves, int method, double kv_
                 const int lo = std::max(pos, bound[uu]), hi = std::min(pos + t, bound[uu + 1]);
                 if (hi <= lo) return false;                                        // (an empty list inside a block's span: cannot happen)
                 if (njobs[uu] >= J) return false;
-                out.table[(size_t)jo * kWordsPerWg + uu * J + njobs[uu]++] = job_word(b - 1, lo - pos, hi - lo, uu - u_first, pieces);
+                if ((lo - pos) % gran || (hi - lo) % gran) return false;            // (cannot happen: every boundary is a multiple)
+                out.table[(size_t)jo * kWordsPerWg + uu * J + njobs[uu]++] = job_word(b - 1, (lo - pos) / gran, (hi - lo) / gran, uu - u_first, pieces);
             }
             pos += t;
         }
@@ -612,15 +636,18 @@ bool make_plan(int64_t bh, int seq_len, int cus, Plan16 &out, int force_sub, int
     for (int sub = 1; sub <= 2; ++sub) {
         if (force_sub && force_sub != sub) continue;
         const int nblocks = (seq_len + 16 * sub - 1) / (16 * sub);
-        if (sub * nblocks > kMaxTiles) continue;
+        if (sub * nblocks > (sub == 2 ? 2 : 1) * kMaxTiles || nblocks > 255) continue;
         // one workgroup per CU; a block is never shared between workgroups
         const int G = (int)std::min<int64_t>(std::min<int64_t>(cus / bh, nblocks), kMaxWgs);
         if (G < 1) continue;
         for (int waves = 4; waves <= 8; waves += 4) {
             if (force_waves && force_waves != waves) continue;
-            for (int method = 0; method < 2; ++method) {
+            bool built = false;
+            for (int method = 0; method < 4; ++method) {
+                if (method == 2 && built) break;                      // the mixed order only where the plain one does not fit
                 Plan16 cand;
                 if (!build(nblocks, sub, G, waves, method, (double)bh * seq_len * 512.0 / 1048576.0, cand)) continue;
+                built = true;
                 if (!best.ok || cand.cycles < best.cycles) { best = cand; best.ok = true; }
             }
         }
@@ -662,6 +689,7 @@ int launch(const Plan16 &plan, const float *q, const float *k, const float *v, f
     p.wgs_per_bh = plan.wgs_per_bh;
     p.total_wgs = (int)(bh * plan.wgs_per_bh);
     p.per_xcd = (p.total_wgs + 7) / 8;
+    p.gshift = plan.granule == 2 ? 1 : 0;
     p.heads_magic = 0xffffffffu / (unsigned)num_heads;
     p.wgs_magic = 0xffffffffu / (unsigned)plan.wgs_per_bh;
     memcpy(p.table, plan.table, sizeof(p.table));

@@ -23,13 +23,14 @@ constexpr int kMaxWaves = 8;             // waves per workgroup: 4 (one per SIMD
 constexpr int kWordsPerWg = 32;          // job words per workgroup: 4 waves x 8 jobs, or 8 waves x 4 jobs
 constexpr int kMaxWgs = 28;              // workgroups per (b,h) the table holds
 constexpr int kTableWords = kMaxWgs * kWordsPerWg;
-constexpr int kMaxTiles = 255;           // key tiles a job word can count (the longest block's tiles: seq_len <= 4080)
+constexpr int kMaxTiles = 255;           // granules of key tiles a job word can count (a granule = one tile, or two for 32-row blocks
+                                         // of more than 255 tiles: seq_len <= 4080 with 16-row blocks, <= 8160 with 32-row blocks)
 
 // One job = one run of key tiles of one query block, computed by one wave.
 //   bits  0-7   block index b (query rows [16 sub b, 16 sub (b + 1)); its key tiles are 0 .. sub (b + 1) - 1; tile
 //               sub b + s is the diagonal tile of the block's half s, later tiles are masked for that half)
-//   bits  8-15  first tile of the run
-//   bits 16-23  tiles in the run (0 = no job: the rest of the wave's list is empty)
+//   bits  8-15  first tile of the run        } in granules of Plan16::granule tiles (1, or 2 where a block has more
+//   bits 16-23  tiles in the run             } than 255 tiles); 0 tiles = no job: the rest of the wave's list is empty
 //   bits 24-26  rank of this piece among the block's pieces (0 = the piece that starts the block)
 //   bits 27-30  pieces the block is cut into (1 = whole: the wave stores O itself; up to 8, on consecutive lists)
 //   bit  31     (first word of every list of the workgroup) some block of this workgroup is cut: the waves meet at a barrier
@@ -44,6 +45,7 @@ constexpr unsigned kWgMergesBit = 0x80000000u;
 struct Plan16 {
     bool ok = false;
     int sub = 1;                         // 16-row halves per query block: 1 or 2 (kernel template)
+    int granule = 1;                     // tiles per count of a job word's first-tile / tiles fields (1 or 2)
     int waves = 4;                       // waves per workgroup: 4 or 8 (kernel template); jobs per wave = 32 / waves
     bool contig = false;                 // workgroup -> (b,h) map: false = grid (workgroup, (b,h)); true = 1-D, every XCD a
                                          // contiguous run of the (b,h)-major list (K / V of a (b,h) through one XCD's L2)

@@ -584,11 +584,13 @@ def test_random_shapes_fuzz(gpu_device):
     assert worst <= 1e-5, worst          # randn inputs: observed ~1e-6
 
 
-@pytest.mark.parametrize("B,H,T", [(1, 16, 2048), (1, 12, 3072), (1, 25, 2048), (1, 12, 4000), (2, 12, 2048), (1, 16, 3000)])
+@pytest.mark.parametrize("B,H,T", [(1, 16, 2048), (1, 12, 3072), (1, 25, 2048), (1, 12, 4000), (2, 12, 2048), (1, 16, 3000), (1, 12, 4096),
+                                   (1, 12, 6144), (1, 12, 4097), (3, 12, 3000)])
 def test_single_long_prompts(B, H, T, gpu_device):
-    """Single long prompts (packed tables with eight segments per workgroup where they fit, the analytic plan or wave pairs
-    beyond): the whole output against the oracle's formula in float64, every element written, strided (packed-QKV) inputs,
-    with the workspace and without it."""
+    """Single long prompts (packed tables with eight segments per workgroup where they fit; beyond, the 16-key-tile kernel with
+    32-row blocks -- job lists cut at tile granularity, job words that count PAIRS of tiles past T = 4080 -- or wave pairs):
+    the whole output against the oracle's formula in float64, every element written, strided (packed-QKV) inputs, with the
+    workspace and without it."""
     torch.manual_seed(T + H)
     d = 64 * H
     qkv = torch.randn(B, T, 3 * d, device=gpu_device)
@@ -600,9 +602,11 @@ def test_single_long_prompts(B, H, T, gpu_device):
         cmhsa.attention_fwd(q, k, v, H, out=out, workspace=workspace)
         assert torch.isfinite(out).all()
         assert (out.double() - want).abs().max().item() <= 1e-5, (B, H, T, workspace is not None)
-    if (B, H, T) in ((1, 16, 2048), (1, 12, 3072)):
-        plan = cmhsa.plan_dump(B, T, H, True)
-        assert plan["use_table"] and plan["segs"] == 8, plan
+    plan = cmhsa.plan_dump(B, T, H, True)
+    if (B, H, T) == (1, 16, 2048):
+        assert plan["family"] == "units32" and plan["use_table"] and plan["segs"] == 8, plan
+    if T >= 3000 and H == 12:
+        assert plan["family"] == "tiles16" and plan["sub"] == 2 and plan["waves"] == 8 and plan["granule"] == (2 if T > 4080 else 1), plan
 
 
 def test_random_larger_grids_fuzz(gpu_device):

@@ -38,7 +38,8 @@ def check_tiles16_plan(plan, B, T, H, cus):
     nblocks = (T + 16 * sub - 1) // (16 * sub)
     assert sub in (1, 2) and W in (4, 8) and J == 32 // W and plan["blocks"] == nblocks, tag
     assert 1 <= plan["wgs_per_bh"] <= 28 and B * H * plan["wgs_per_bh"] <= cus, tag
-    assert sub * nblocks <= 255, tag
+    gran = plan["granule"]                                          # a job word counts tiles in granules (8-bit fields)
+    assert gran in (1, 2) and sub * nblocks <= 255 * gran and nblocks <= 255 and (gran == 1 or sub == 2), tag
     if plan["contig"]:
         assert plan["grid_x"] % 8 == 0 and plan["grid_x"] >= B * H * plan["wgs_per_bh"] and plan["grid_y"] == 1, tag
     else:
@@ -57,6 +58,7 @@ def check_tiles16_plan(plan, B, T, H, cus):
             later = first = 0
             for blk, lo, cnt, rank, pieces in jobs:
                 assert 0 <= blk < nblocks and cnt >= 1 and lo + cnt <= sub * (blk + 1), (tag, j, u, blk, lo, cnt)
+                assert lo % gran == 0 and cnt % gran == 0 and cnt // gran <= 255 and lo // gran <= 255, (tag, j, u, blk, lo, cnt)
                 assert 1 <= pieces <= W and rank < pieces, (tag, j, u)
                 cov[blk].append((lo, cnt, rank, pieces, j, u))
                 if pieces > 1:
@@ -246,7 +248,7 @@ import cmhsa
 cmhsa.LIB_PATH = %r
 import test_plan
 n = 0
-for B, H, T in itertools.product((1, 2, 3, 5, 8, 16), (1, 3, 12, 16, 25), (1, 15, 16, 17, 31, 33, 64, 100, 255, 256, 500, 512, 777, 1000, 1024, 1536, 2048, 4000, 4064)):
+for B, H, T in itertools.product((1, 2, 3, 5, 8, 16), (1, 3, 12, 16, 25), (1, 15, 16, 17, 31, 33, 64, 100, 255, 256, 500, 512, 777, 1000, 1024, 1536, 2048, 4000, 4064, 4097, 6000, 8160)):
     for cus in (256, 104):
         plan = cmhsa.plan_dump(B, T, H, False, cus)
         if plan["family"] == "tiles16":
@@ -271,6 +273,9 @@ def test_baseline_configs_pick_the_documented_families():
         assert c5["waves"] == 1 and not c5["longest_first"] and c5["wgs_per_bh"] == 64
     c4 = cmhsa.plan_dump(64, 512, 25, True, 256)                   # config 4's attention shape on one GPU: one round of job lists
     assert c4["family"] == "lists" and c4["period_bh"] == 25 and c4["lists_per_period"] == 32 and c4["units_per_list"] <= 110
+    for T, gran in ((3072, 1), (4096, 2), (6144, 2)):              # single long prompts: 32-row blocks on 16-key tiles, job lists
+        lp = cmhsa.plan_dump(1, T, 12, True, 256)
+        assert lp["family"] == "tiles16" and lp["sub"] == 2 and lp["waves"] == 8 and lp["granule"] == gran and lp["wgs_per_bh"] == 21
     mid = cmhsa.plan_dump(16, 1024, 12, True, 256)                 # 1.5 rounds of pairs -> longest first
     assert mid["waves"] == 1 and mid["longest_first"] == 192
 
