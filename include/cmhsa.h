@@ -93,8 +93,10 @@ int cmhsa_fp32_fwd_ws(const float *q, const float *k, const float *v, float *o,
  * It is cmhsa_fp32_fwd_ws with the workspace taken from a static array in device memory that the library's code
  * object carries: CMHSA_NOALLOC_SCRATCH_BYTES (1 MiB) on every GPU the library runs on, held until the process ends.
  * The call allocates nothing (no hipMalloc / hipFree, no allocating library routine); the array's address on the
- * current device is looked up once per device (hipGetSymbolAddress, at the first call on that device: a host-side
- * query, not a stream operation -- make a device's first call outside graph capture, as with any set-up).
+ * current device is looked up once per device (hipGetSymbolAddress, at the first call on that device).  The first call
+ * for a (device, shape) also builds the shape's plan and may raise a kernel's dynamic-LDS limit: host-side set-up that does
+ * not belong in a capture -- make ONE un-captured call per (device, shape) before capturing it (tests/test_zz_no_alloc.py
+ * captures and replays the call after such a warm-up).
  *   - A shape whose plan needs more scratch than the array holds is rejected with CMHSA_ERR_WORKSPACE (nothing is
  *     launched); cmhsa_fp32_fwd_workspace_bytes() tells the need in advance.  BASELINE config 2 needs 0.8 MiB.
  *   - Every call on a GPU shares that GPU's array: calls that OVERLAP in time on one GPU (different streams) race.
@@ -110,7 +112,10 @@ int cmhsa_fp32_fwd_noalloc(const float *q, const float *k, const float *v, float
 /* CMHSA_WORKSPACE_BYTES as a function (for bindings that cannot read the macro). */
 size_t cmhsa_workspace_bytes(void);
 
-/* Zeroes the workspace's counter block (the first 16 KiB) on `stream`; call once after allocating it. */
+/* Zeroes the workspace's counter block (the first 16 KiB) on `stream`; call once after allocating it.  Also the one place
+ * where the memory's kind is checked: anything but ordinary (coarse-grained, hipMalloc'd) device memory -- managed,
+ * fine-grained, host-mapped or unregistered -- is refused with CMHSA_ERR_WORKSPACE, because the hand-off between the
+ * workgroups that share a split query block relies on write-through stores reaching the memory side (see cmhsa_fp32_fwd_ws). */
 int cmhsa_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 
 /* Workspace bytes the plan of this shape uses on the current device (0: the plan splits no query block). */

@@ -898,8 +898,9 @@ const char *cmhsa_status_string(int status) {
         case CMHSA_ERR_HEAD_DIM: return "Head dimension must be 64.";
         case CMHSA_ERR_ALIGNMENT: return "pointers must be 16-byte aligned and row/batch strides multiples of 4 for float4 loads to work";
         case CMHSA_ERR_TOO_LARGE: return "problem too large for 32-bit tile indexing";
-        case CMHSA_ERR_WORKSPACE: return "workspace too small (cmhsa_fp32_fwd_noalloc: this shape's plan needs more than the static "
-                                         "CMHSA_NOALLOC_SCRATCH_BYTES; use cmhsa_fp32_fwd_ws with a workspace, or cmhsa_fp32_fwd)";
+        case CMHSA_ERR_WORKSPACE: return "workspace too small or not ordinary device memory (cmhsa_workspace_init: hipMalloc'd memory of at "
+                                         "least 16 KiB, not managed / host-mapped; cmhsa_fp32_fwd_noalloc: this shape's plan needs more than "
+                                         "the static CMHSA_NOALLOC_SCRATCH_BYTES; use cmhsa_fp32_fwd_ws with a workspace, or cmhsa_fp32_fwd)";
         default: return status > 0 ? hipGetErrorString((hipError_t)status) : "unknown cmhsa status";
     }
 }
@@ -1069,6 +1070,17 @@ int cmhsa_workspace_init(void *workspace, size_t workspace_bytes, void *stream) 
     if (!workspace) return CMHSA_ERR_NULL_POINTER;
     if ((uintptr_t)workspace & 255) return CMHSA_ERR_ALIGNMENT;
     if (workspace_bytes < kWsCounterBytes) return CMHSA_ERR_WORKSPACE;
+    // The hand-off between the workgroups that share a split block (sc1 stores, drained, one agent-scope counter add, sc1
+    // loads, no fence) is sufficient for ordinary device memory -- coarse-grained hipMalloc memory, where an sc1 store
+    // writes through to the memory side and an sc1 load misses the reader's L2 -- and is measured for that only (MI355X
+    // guide, visibility table row 1).  Managed, fine-grained or host-mapped memory is refused here, once, instead of
+    // silently merging stale partials.
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, workspace) != hipSuccess) {
+        (void)hipGetLastError();                                     // (an unregistered pointer: not device memory either)
+        return CMHSA_ERR_WORKSPACE;
+    }
+    if (attr.type != hipMemoryTypeDevice || attr.isManaged) return CMHSA_ERR_WORKSPACE;
     const hipError_t e = hipMemsetAsync(workspace, 0, kWsCounterBytes, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? CMHSA_OK : (int)e;
 }

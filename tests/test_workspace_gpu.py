@@ -126,6 +126,30 @@ def test_short_or_missing_workspace_selects_the_plan_without_parts(gpu_device):
     assert lib.cmhsa_fp32_fwd_ws(*args(out_b), ctypes.c_void_p(ws.buffer.data_ptr() + 64), ws.nbytes - 64, stream) == cmhsa.CMHSA_ERR_ALIGNMENT
 
 
+def test_workspace_init_refuses_memory_that_is_not_ordinary_device_memory(gpu_device):
+    """The merge of a split block relies on write-through stores reaching the memory side (coarse-grained hipMalloc
+    memory); cmhsa_workspace_init asks the runtime what the pointer is and refuses pinned host memory (a valid device
+    pointer on this platform), an unregistered host pointer and a short buffer; device memory passes."""
+    import ctypes
+
+    lib = cmhsa.load_library()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+    nbytes = int(lib.cmhsa_workspace_bytes())
+    dev_buf = torch.empty(nbytes, dtype=torch.uint8, device=gpu_device)
+    assert lib.cmhsa_workspace_init(ctypes.c_void_p(dev_buf.data_ptr()), nbytes, stream) == cmhsa.CMHSA_OK
+    pinned = torch.empty(nbytes + 256, dtype=torch.uint8).pin_memory()
+    p = (pinned.data_ptr() + 255) // 256 * 256
+    assert lib.cmhsa_workspace_init(ctypes.c_void_p(p), nbytes, stream) == cmhsa.CMHSA_ERR_WORKSPACE
+    plain = torch.empty(nbytes + 256, dtype=torch.uint8)
+    p = (plain.data_ptr() + 255) // 256 * 256
+    assert lib.cmhsa_workspace_init(ctypes.c_void_p(p), nbytes, stream) == cmhsa.CMHSA_ERR_WORKSPACE
+    assert lib.cmhsa_workspace_init(ctypes.c_void_p(dev_buf.data_ptr()), 1024, stream) == cmhsa.CMHSA_ERR_WORKSPACE
+    torch.cuda.synchronize(gpu_device)
+    # the refusals leave no sticky error behind: the next launch works
+    q = torch.randn(1, 64, 128, device=gpu_device)
+    assert torch.isfinite(cmhsa.attention_fwd(q, q, q, 2)).all()
+
+
 def test_torch_op_uses_its_per_stream_workspace(gpu_device):
     import causal_multihead_self_attention  # noqa: F401
 

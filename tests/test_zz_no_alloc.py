@@ -92,3 +92,36 @@ def test_noalloc_entry_point_limits_and_checks(gpu_device):
     # the usual argument checks
     assert lib.cmhsa_fp32_fwd_noalloc(*_args(q, k, v, o, B, T, H)[:15], 32, stream) == cmhsa.CMHSA_ERR_HEAD_DIM
     assert lib.cmhsa_fp32_fwd_noalloc(*_args(q, k, v, o, B, 0, H), stream) == 0
+
+
+def test_noalloc_entry_point_captured_in_a_hip_graph(gpu_device):
+    """What the entry point is for: a call under HIP graph capture.  One un-captured call per (device, shape) first (it takes
+    the scratch array's address, raises the kernel's LDS limit and builds the shape's plan: host-side set-up that does not
+    belong in a capture); then the same call captured on a side stream, replayed three times on changing inputs: every replay
+    bit-equal to the eager workspace call on the same inputs."""
+    lib = cmhsa.load_library()
+    B, T, H = 1, 1024, 12
+    ws = cmhsa.Workspace(gpu_device)
+    q, k, v = (t.contiguous() for t in _inputs(B, T, H, 80, gpu_device))
+    out = torch.empty((B, T, 64 * H), device=gpu_device)
+    side = torch.cuda.Stream(gpu_device)
+    with torch.cuda.stream(side):
+        assert lib.cmhsa_fp32_fwd_noalloc(*_args(q, k, v, out, B, T, H), ctypes.c_void_p(side.cuda_stream)) == 0     # the warm-up call
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rc = lib.cmhsa_fp32_fwd_noalloc(*_args(q, k, v, out, B, T, H), ctypes.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream))
+    assert rc == 0
+    for seed in (81, 82, 83):
+        nq, nk, nv = _inputs(B, T, H, seed, gpu_device)
+        q.copy_(nq); k.copy_(nk); v.copy_(nv)
+        out.fill_(float("nan"))
+        torch.cuda.synchronize(gpu_device)
+        graph.replay()
+        torch.cuda.synchronize(gpu_device)
+        want = torch.empty_like(out)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)
+        assert lib.cmhsa_fp32_fwd_ws(*_args(q, k, v, want, B, T, H), ws.ptr, ws.nbytes, stream) == 0
+        torch.cuda.synchronize(gpu_device)
+        assert torch.equal(out, want), seed
+
