@@ -498,10 +498,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void cmhsa_fwd_kernel(Params p) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 0 on the first unit (m_run = -inf)
                 l_run *= alpha;
                 m_run = m_new;
+                if (!fresh) {                  // (a block's first unit: O is zero already -- 32 multiplies that each wait for a gap
+                                               //  in the SIMD partner's MFMA stream)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o0[r] *= alpha;
-                    o1[r] *= alpha;
+                    for (int r = 0; r < 16; ++r) {
+                        o0[r] *= alpha;
+                        o1[r] *= alpha;
+                    }
                 }
                 psum = 0.f;
 #pragma unroll
