@@ -418,6 +418,23 @@ class Bench:
                                               "plan": self.cmhsa.plan_description(o["B"], o["T"], o["H"], self.workspace.nbytes)}
         del q, k, v, oo, want
         torch.cuda.empty_cache()
+        # three more shapes of the path, each on the plan family built for it in round 3: config 4's attention shape on one
+        # GPU (GPT2-XL, 64 prompts, T = 512: job lists), the launches of a B = 1 generation at T = 256 / 512 (config 3: the
+        # 16-key-tile kernel) and a single long prompt (32-row blocks on the 16-key tiles); 2 000 / 300 warm-up launches
+        # because the shader clock needs ~20 ms of load to settle (timing.device_ramp)
+        for name, (B, T, H), reps, warm in (("config4_attention_shape_b64_h25_t512", (64, 512, 25), 100, 300),
+                                            ("config3_launch_b1_h12_t256", (1, 256, 12), 1000, 2000),
+                                            ("config3_launch_b1_h12_t512", (1, 512, 12), 1000, 2000),
+                                            ("single_long_prompt_b1_h12_t4096", (1, 4096, 12), 100, 300)):
+            q, k, v = self.sliced_inputs(B, T, H)
+            oo = torch.empty((B, T, 64 * H), device=self.dev)
+            a = self.fwd_args(q, k, v, oo, B, T, H)
+            us = self.events_us(lambda: self.launch(a), reps=reps, warm=warm)
+            tf = self.cmhsa.algorithmic_flops(B, T, H, 64) / us / 1e6
+            others[name] = {"us_per_launch": round(us, 2), "tflops": round(tf, 2), "frac_of_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                            "warmup": warm, "reps": reps, "plan": self.cmhsa.plan_description(B, T, H, self.workspace.nbytes).split(", workspace")[0]}
+            del q, k, v, oo
+        torch.cuda.empty_cache()
         # SURVEY 8(d) config 2 asks for more than the headline: contiguous as well as QKV-sliced inputs, randn as well
         # as rand, and the latency of ONE launch (launch -> completion seen by the host) next to the back-to-back rate
         c2 = WORKLOADS["config2"]
